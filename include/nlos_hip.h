@@ -1,0 +1,228 @@
+/*
+ * nlos_hip.h -- C ABI of libnlos_hip.so, the MI355X (gfx950) transient renderer.
+ *
+ * Drop-in boundary for the native interface of cmu-ci-lab/nlos_surface_optimization
+ * (paths relative to transient_rendering_cython/ in the reference):
+ *   - section 1 mirrors, parameter for parameter, the C++ free functions the
+ *     reference's Cython modules bind (`cdef extern from "...h"`); they take HOST
+ *     pointers, are synchronous and stateless, and return an int status where the
+ *     reference returns void (0 = ok, see nlos_last_error()).
+ *   - section 2 is the device-resident family (device pointers + hipStream_t as
+ *     void*), an allowed addition (SURVEY.md section 8b "Ownership") used by the
+ *     torch path, the benchmark and the multi-GPU source sharding.
+ * Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ */
+#ifndef NLOS_HIP_H
+#define NLOS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NLOS_OK              0
+#define NLOS_ERR_ARG        -1
+#define NLOS_ERR_HIP        -2
+#define NLOS_ERR_NO_DEVICE  -3
+
+/* thread-local message of the last failing call */
+const char *nlos_last_error(void);
+/* number of visible HIP devices (0 when none / no driver); never throws */
+int nlos_device_count(void);
+/* library version: major*10000 + minor*100 + patch */
+int nlos_version(void);
+
+/* ------------------------------------------------------------------------
+ * Section 1 -- host-pointer drop-ins (reference signatures)
+ * ------------------------------------------------------------------------ */
+
+/* smoothed_transient/stratifiedStreamedTransientRenderer.h:3-5 (v2 forward;
+ * vertexNormal / vertexAlbedo may be NULL) */
+int nlos_streamed_render_transient(float *origin, int numSources, float *normal,
+        float *vertices, int numVertices, float *vertexNormal, float *vertexAlbedo,
+        int *triangles, int numTriangles, int numSamples, float lowerBound,
+        float upperBound, float resolution, double *transient, double *pathlengths,
+        int refine_scale, int sigma_bin);
+
+/* smoothed_transient/stratifiedStreamedTransientRenderer.h (streamed_render_intensity);
+ * intensity[numTriangles] is accumulated into */
+int nlos_streamed_render_intensity(float *origin, int numSources, float *normal,
+        float *vertices, int numVertices, float *vertexNormal, int *triangles,
+        int numTriangles, int numSamples, float lowerBound, float upperBound,
+        double *intensity);
+
+/* smoothed_transient/stratifiedStreamedGradientRenderer.h:3-13 */
+int nlos_streamed_render_gradient(double *data, double *weight, float *origin,
+        int measurement, float *normal, float *vertices, int numVertices,
+        float *vertexNormal, int *triangles, int numTriangles, int numSamples,
+        float lowerBound, float upperBound, float resolution, double *transient,
+        double *pathlengths, double *gradient, int refine_scale, int sigma_bin,
+        int testing_flag, int loss_test);
+
+int nlos_streamed_render_gradient_w_albedo(double *data, double *weight, float *origin,
+        int measurement, float *normal, float *vertices, int numVertices,
+        float *albedo, int *triangles, int numTriangles, int numSamples,
+        float lowerBound, float upperBound, float resolution, double *transient,
+        double *pathlengths, double *gradient, int refine_scale, int sigma_bin,
+        int testing_flag, int loss_test);
+
+/* reference returns the scalar; here it is written to *grad_out */
+int nlos_streamed_render_gradient_albedo(double *data, double *weight, float *origin,
+        int measurement, float *normal, float *vertices, int numVertices,
+        float *albedo, int *triangles, int numTriangles, int numSamples,
+        float lowerBound, float upperBound, float resolution, double *transient,
+        double *pathlengths, int refine_scale, int sigma_bin, int testing_flag,
+        int loss_test, double *grad_out);
+
+/* gradient is [numBins,3], accumulated into (renderer.pyx:78-88) */
+int nlos_streamed_render_vertex_gradient(int vertex_num, float *origin, int measurement,
+        float *normal, float *vertices, int numVertices, int *triangles,
+        int numTriangles, int numSamples, float lowerBound, float upperBound,
+        float resolution, double *gradient, int refine_scale, int sigma_bin);
+
+/* ggx/stratifiedStreamed{Transient,Gradient}Renderer.h: as above with `float alpha`
+ * after numTriangles */
+int nlos_ggx_streamed_render_transient(float *origin, int numSources, float *normal,
+        float *vertices, int numVertices, float *vertexNormal, float *vertexAlbedo,
+        int *triangles, int numTriangles, float alpha, int numSamples, float lowerBound,
+        float upperBound, float resolution, double *transient, double *pathlengths,
+        int refine_scale, int sigma_bin);
+int nlos_ggx_streamed_render_intensity(float *origin, int numSources, float *normal,
+        float *vertices, int numVertices, float *vertexNormal, int *triangles,
+        int numTriangles, float alpha, int numSamples, float lowerBound,
+        float upperBound, double *intensity);
+int nlos_ggx_streamed_render_gradient(double *data, double *weight, float *origin,
+        int measurement, float *normal, float *vertices, int numVertices,
+        float *vertexNormal, int *triangles, int numTriangles, float alpha,
+        int numSamples, float lowerBound, float upperBound, float resolution,
+        double *transient, double *pathlengths, double *gradient, int refine_scale,
+        int sigma_bin, int testing_flag);
+int nlos_ggx_streamed_render_gradient_alpha(double *data, double *weight, float *origin,
+        int measurement, float *normal, float *vertices, int numVertices,
+        float *vertexNormal, int *triangles, int numTriangles, float alpha,
+        int numSamples, float lowerBound, float upperBound, float resolution,
+        double *transient, double *pathlengths, int refine_scale, int sigma_bin,
+        double *grad_out);
+
+/* stratified_transient_raytracer/stratifiedStreamedGradientRenderer.h:4 (v1) and
+ * stratifiedStreamedTransientRenderer.h (v1 forward, unclamped form factor) */
+int nlos_v1_streamed_render_gradient(double *data, float *origin, int measurement,
+        float *normal, float *vertices, int numVertices, int *triangles,
+        int numTriangles, int numSamples, float lowerBound, float upperBound,
+        float resolution, int w_width, double *transient, double *pathlengths,
+        double *gradient);
+int nlos_v1_streamed_render_transient(float *origin, int numSources, float *normal,
+        float *vertices, int numVertices, float *vertexNormal, float *vertexAlbedo,
+        int *triangles, int numTriangles, int numSamples, float lowerBound,
+        float upperBound, float resolution, double *transient, double *pathlengths);
+
+/* embree_intersector/c_embree_intersector.h:3-9 */
+int nlos_embree3_tbb_line_intersection(float *origins, float *directions, int num_ray,
+        float *vertices, int num_vertices, int *triangles, int num_triangles,
+        float *intersect /* [num_ray,3] */);
+int nlos_embree3_tbb_short_line_intersection(float *origins, float *directions,
+        int num_ray, float *vertices, int num_vertices, int *triangles,
+        int num_triangles, float *intersect /* [num_ray] */);
+/* barycentric_to_world (c_embree_intersector.h:4) takes no array sizes; the device
+ * path needs them to stage V and F, so the two counts are added */
+int nlos_barycentric_to_world_n(float *vertices, int num_vertices, int *triangles,
+        int num_triangles, float *barycoord, int num_ray, float *intersection_p);
+
+/* process-wide knobs used by the host-pointer drop-ins (the reference has none:
+ * its RNG seeding is fixed, STR/sampler.cpp:20-34) */
+void nlos_set_default_seed(uint64_t seed);
+void nlos_set_default_device(int device);
+
+/* ------------------------------------------------------------------------
+ * Section 2 -- device-resident family
+ * ------------------------------------------------------------------------ */
+typedef struct nlos_ctx nlos_ctx;   /* per-device scratch: BVH, visibility cache, residual */
+
+int  nlos_ctx_create(int device, nlos_ctx **out);
+void nlos_ctx_destroy(nlos_ctx *ctx);
+/* bytes of device scratch currently held */
+int64_t nlos_ctx_scratch_bytes(const nlos_ctx *ctx);
+
+enum {
+    NLOS_MODE_TRANSIENT       = 0,  /* rows S,I,F,FD */
+    NLOS_MODE_GRADIENT        = 1,  /* + D,G,GD */
+    NLOS_MODE_INTENSITY       = 2,  /* row X */
+    NLOS_MODE_GRAD_ALBEDO     = 3,  /* row A  */
+    NLOS_MODE_GRAD_ALPHA      = 4,  /* GGX d/d alpha */
+    NLOS_MODE_VERTEX_GRADIENT = 5,  /* single-vertex per-bin gradient */
+    NLOS_MODE_GRADIENT_V1     = 6   /* rows W,G1 */
+};
+
+/* All pointers are DEVICE pointers (same dtypes/layouts as section 1). */
+typedef struct nlos_render_args {
+    int32_t mode;
+    /* sources (this rank's block) */
+    const float *origin;        /* [L,3] */
+    const float *normal;        /* [L,3] */
+    int32_t L;
+    int64_t source_offset;      /* global index of origin[0]; keys the RNG */
+    int32_t total_sources;      /* global L for the 1/L normalisation; 0 -> L */
+    /* mesh */
+    const float *vertices;      /* [V,3] */
+    int32_t V;
+    const int32_t *faces;       /* [F,3] */
+    int32_t F;
+    const float *vertex_normal; /* [V,3] or NULL */
+    const float *albedo;        /* [V]   or NULL */
+    /* sampling / binning */
+    int32_t num_samples;
+    float lower_bound, upper_bound, resolution;
+    int32_t refine_scale, sigma_bin;
+    uint64_t seed;
+    /* measurement */
+    const double *data;         /* [L,T] */
+    const double *weight;       /* [L,T] (NULL -> 1) */
+    /* outputs */
+    double *transient;          /* [L,T]  overwritten */
+    double *pathlengths;        /* [T]    overwritten (may be NULL) */
+    double *gradient;           /* [V,3] accumulated into ([T,3] for VERTEX_GRADIENT;
+                                   zeroed first for GRADIENT_V1) */
+    double *intensity;          /* [F]   accumulated into */
+    double *scalar_out;         /* [1]   overwritten (GRAD_ALBEDO / GRAD_ALPHA) */
+    /* flags */
+    int32_t testing_flag, loss_test;
+    int32_t normal_term;        /* -1 reference rule, 0 off, 1 on */
+    int32_t clamp;              /* 1 v2 (default), 0 v1 unclamped forward */
+    int32_t use_ggx;
+    float   ggx_alpha;
+    int32_t vertex_num;         /* VERTEX_GRADIENT */
+    int32_t w_width;            /* GRADIENT_V1 */
+    int32_t reuse_bvh;          /* 1: vertices/faces unchanged since the previous call on this ctx */
+    /* autograd support (additions; the reference always derives the residual itself) */
+    const double *residual;     /* [L,T] or NULL. GRADIENT: use this as `difference` instead of
+                                   (data - transient) * weight; data/weight may then be NULL */
+    int32_t keep_visibility;    /* TRANSIENT: also record the per-sample visibility cache */
+    int32_t reuse_visibility;   /* GRADIENT with residual: skip pass 1, reuse the cache recorded by the
+                                   previous render on this ctx (same mesh, sources, samples, seed) */
+} nlos_render_args;
+
+void nlos_render_args_init(nlos_render_args *a);   /* zero + defaults (clamp=1, normal_term=-1, refine=1, sigma_bin=1) */
+
+/* Enqueue one render on `stream` (hipStream_t as void*; NULL = default stream).
+ * Asynchronous: returns after the launches are queued. */
+int nlos_render(nlos_ctx *ctx, const nlos_render_args *args, void *stream);
+
+/* closest-hit batch (row E) on device pointers: out3 [N,3] and/or out1 [N] */
+int nlos_intersect(nlos_ctx *ctx, const float *origins, const float *dirs, int n_rays,
+                   const float *vertices, int V, const int32_t *faces, int F,
+                   float *out3, float *out1, void *stream);
+
+/* number of bins the reference computes in float32: ceil((ub-lb)/res) */
+int nlos_num_bins(float lower_bound, float upper_bound, float resolution);
+
+/* timing of the kernels of the last nlos_render on this ctx, measured with HIP
+ * events on the launch stream (ms): [0]=bvh build, [1]=forward, [2]=residual,
+ * [3]=gradient; valid after the stream is synchronised.  enable first. */
+void nlos_ctx_enable_timing(nlos_ctx *ctx, int enable);
+int  nlos_ctx_last_timing(nlos_ctx *ctx, float *ms4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,153 @@
+"""ctypes binding of libnlos_hip.so (the C ABI declared in include/nlos_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no AMD GPU is
+visible when a render is requested, the call raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnlos_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_lib = None
+
+c_f32p = ctypes.c_void_p
+c_f64p = ctypes.c_void_p
+c_i32p = ctypes.c_void_p
+
+
+class NlosError(RuntimeError):
+    """A libnlos_hip call returned a non-zero status."""
+
+
+class RenderArgs(ctypes.Structure):
+    """Mirror of `nlos_render_args` (include/nlos_hip.h, section 2)."""
+    _fields_ = [
+        ("mode", ctypes.c_int32),
+        ("origin", ctypes.c_void_p),
+        ("normal", ctypes.c_void_p),
+        ("L", ctypes.c_int32),
+        ("source_offset", ctypes.c_int64),
+        ("total_sources", ctypes.c_int32),
+        ("vertices", ctypes.c_void_p),
+        ("V", ctypes.c_int32),
+        ("faces", ctypes.c_void_p),
+        ("F", ctypes.c_int32),
+        ("vertex_normal", ctypes.c_void_p),
+        ("albedo", ctypes.c_void_p),
+        ("num_samples", ctypes.c_int32),
+        ("lower_bound", ctypes.c_float),
+        ("upper_bound", ctypes.c_float),
+        ("resolution", ctypes.c_float),
+        ("refine_scale", ctypes.c_int32),
+        ("sigma_bin", ctypes.c_int32),
+        ("seed", ctypes.c_uint64),
+        ("data", ctypes.c_void_p),
+        ("weight", ctypes.c_void_p),
+        ("transient", ctypes.c_void_p),
+        ("pathlengths", ctypes.c_void_p),
+        ("gradient", ctypes.c_void_p),
+        ("intensity", ctypes.c_void_p),
+        ("scalar_out", ctypes.c_void_p),
+        ("testing_flag", ctypes.c_int32),
+        ("loss_test", ctypes.c_int32),
+        ("normal_term", ctypes.c_int32),
+        ("clamp", ctypes.c_int32),
+        ("use_ggx", ctypes.c_int32),
+        ("ggx_alpha", ctypes.c_float),
+        ("vertex_num", ctypes.c_int32),
+        ("w_width", ctypes.c_int32),
+        ("reuse_bvh", ctypes.c_int32),
+        ("residual", ctypes.c_void_p),
+        ("keep_visibility", ctypes.c_int32),
+        ("reuse_visibility", ctypes.c_int32),
+    ]
+
+
+MODE_TRANSIENT = 0
+MODE_GRADIENT = 1
+MODE_INTENSITY = 2
+MODE_GRAD_ALBEDO = 3
+MODE_GRAD_ALPHA = 4
+MODE_VERTEX_GRADIENT = 5
+MODE_GRADIENT_V1 = 6
+
+# every symbol include/nlos_hip.h declares: name -> (restype, argtypes)
+_I, _F, _P, _U64, _I64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int64
+SYMBOLS = {
+    "nlos_last_error": (ctypes.c_char_p, []),
+    "nlos_device_count": (_I, []),
+    "nlos_version": (_I, []),
+    "nlos_streamed_render_transient": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _I, _I]),
+    "nlos_streamed_render_intensity": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _I, _F, _F, _P]),
+    "nlos_streamed_render_gradient": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _I, _I, _I, _I]),
+    "nlos_streamed_render_gradient_w_albedo": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _I, _I, _I, _I]),
+    "nlos_streamed_render_gradient_albedo": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F, _P, _P, _I, _I, _I, _I, _P]),
+    "nlos_streamed_render_vertex_gradient": (_I, [_I, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _P, _I, _I]),
+    "nlos_ggx_streamed_render_transient": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _F, _I, _F, _F, _F, _P, _P, _I, _I]),
+    "nlos_ggx_streamed_render_intensity": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _F, _I, _F, _F, _P]),
+    "nlos_ggx_streamed_render_gradient": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _F, _I, _F, _F, _F, _P, _P, _P, _I, _I, _I]),
+    "nlos_ggx_streamed_render_gradient_alpha": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _F, _I, _F, _F, _F, _P, _P, _I, _I, _P]),
+    "nlos_v1_streamed_render_gradient": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _I, _P, _P, _P]),
+    "nlos_v1_streamed_render_transient": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P]),
+    "nlos_embree3_tbb_line_intersection": (_I, [_P, _P, _I, _P, _I, _P, _I, _P]),
+    "nlos_embree3_tbb_short_line_intersection": (_I, [_P, _P, _I, _P, _I, _P, _I, _P]),
+    "nlos_barycentric_to_world_n": (_I, [_P, _I, _P, _I, _P, _I, _P]),
+    "nlos_set_default_seed": (None, [_U64]),
+    "nlos_set_default_device": (None, [_I]),
+    "nlos_ctx_create": (_I, [_I, ctypes.POINTER(ctypes.c_void_p)]),
+    "nlos_ctx_destroy": (None, [_P]),
+    "nlos_ctx_scratch_bytes": (_I64, [_P]),
+    "nlos_render_args_init": (None, [ctypes.POINTER(RenderArgs)]),
+    "nlos_render": (_I, [_P, ctypes.POINTER(RenderArgs), _P]),
+    "nlos_intersect": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _P, _P, _P]),
+    "nlos_num_bins": (_I, [_F, _F, _F]),
+    "nlos_ctx_enable_timing": (None, [_P, _I]),
+    "nlos_ctx_last_timing": (_I, [_P, _P]),
+}
+
+
+def build(force=False):
+    """Compile libnlos_hip.so for gfx950 with hipcc (recipe: csrc/Makefile)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "nlos_hip.h"))
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(s) for s in srcs)
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", CSRC, "-j4", "all"])
+    return LIB_PATH
+
+
+def lib():
+    """Load the shared library (never builds implicitly on a GPU box: ship the .so)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NlosError(
+                "libnlos_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().nlos_last_error()
+        raise NlosError("%s failed (status %d): %s" % (what or "libnlos_hip call", rc,
+                                                      msg.decode() if msg else "?"))
+
+
+def device_count():
+    return int(lib().nlos_device_count())
+
+
+def num_bins(lb, ub, res):
+    return int(lib().nlos_num_bins(lb, ub, res))

@@ -1,0 +1,867 @@
+// nlos_api.hip -- C ABI of libnlos_hip.so (see include/nlos_hip.h).
+//
+// Host-side driver of the render: the counterpart of the reference's
+// streamed_render_transient / streamed_render_gradient drivers
+// (smoothed_transient/stratifiedStreamedTransientRenderer.cpp:81-153,
+//  smoothed_transient/stratifiedStreamedGradientRenderer.cpp:471-578): build the
+// acceleration structure, pass 1, residual, pass 2 -- all enqueued on one HIP
+// stream with no host synchronisation in between.
+#include "../../include/nlos_hip.h"
+#include "nlos_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            return fail(NLOS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));  \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return NLOS_OK;
+        if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(NLOS_ERR_HIP, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+        }
+        cap = want;
+        return NLOS_OK;
+    }
+    void release() {
+        if (p) { hipError_t e = hipFree(p); (void)e; }
+        p = nullptr; cap = 0;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+            if (hipSetDevice(dev) == hipSuccess) changed = true;
+        }
+    }
+    ~DeviceGuard() {
+        if (changed) { hipError_t e = hipSetDevice(prev); (void)e; }
+    }
+};
+
+}  // namespace
+
+struct nlos_ctx {
+    int device = 0;
+    // BVH scratch + outputs
+    DevBuf keys0, keys1, idx0, idx1, child, range, parent, arrive, box, status;
+    DevBuf nodes, tris, facerec, face_id;
+    int built_F = -1, built_V = -1;
+    // render scratch
+    DevBuf vis, diff, fine, taps, rows_tmp, grad_tmp;
+    int tap_refine = -1, tap_sigma = -1; float tap_res = -1.0f; int tap_kind = -1;
+    // host-pointer path staging
+    DevBuf io[12];
+    // what the visibility cache currently describes
+    struct VisKey { int L = -1, F = -1, V = -1, spt = -1; long long off = -1; uint64_t seed = 0; float lb = 0, ub = 0;
+                    int feat = -1; } vis_key;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};
+
+namespace {
+
+std::mutex g_mu;
+std::vector<nlos_ctx*> g_default_ctx;     // per device, for the host-pointer drop-ins
+uint64_t g_default_seed = 0;
+int g_default_device = 0;
+
+int get_default_ctx(nlos_ctx** out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int dev = g_default_device;
+    if ((int)g_default_ctx.size() <= dev) g_default_ctx.resize(dev + 1, nullptr);
+    if (!g_default_ctx[dev]) {
+        int rc = nlos_ctx_create(dev, &g_default_ctx[dev]);
+        if (rc) return rc;
+    }
+    *out = g_default_ctx[dev];
+    return NLOS_OK;
+}
+
+// Gaussian taps of the gradient pass, computed exactly as the reference does
+// (smoothed_transient/transient_and_gradient.cpp:537-547, :973-974): K =
+// 4*refine*sigma_bin+1, sigma = res*sigma_bin/2.355 (float*int, then double),
+// delta_i evaluated in float.  Layout: [w(K) | delta(K) | g(K)].
+void host_taps(int refine, int sigma_bin, float res, std::vector<double>& t) {
+    const int K = 4 * refine * sigma_bin + 1;
+    t.assign(3 * (size_t)K, 0.0);
+    const double sigma = res * sigma_bin / 2.355;
+    const double sigma_square = sigma * sigma;
+    const double normalization = 1 / sigma / std::sqrt(2 * M_PI) * res / refine;
+    for (int i = 0; i < K; ++i) {
+        double tt = (-2 * refine * sigma_bin + i) * res / refine / sigma;
+        t[i] = std::exp(-(tt * tt) / 2) * normalization;
+        float d = (-2 * refine * sigma_bin + i) * res / refine;
+        double dl = (double)d;
+        t[K + i] = dl;
+        t[2 * K + i] = (double)(float)(dl / sigma_square * 2);
+    }
+}
+
+// single unit tap (v1 gradient: delta 0, weight 1)
+void host_taps_unit(std::vector<double>& t) {
+    t.assign(3, 0.0);
+    t[0] = 1.0;
+}
+
+int ensure_taps(nlos_ctx* c, int kind, int refine, int sigma_bin, float res, hipStream_t st, int* K_out) {
+    const int K = kind == 1 ? 1 : 4 * refine * sigma_bin + 1;
+    *K_out = K;
+    if (c->tap_kind == kind && c->tap_refine == refine && c->tap_sigma == sigma_bin && c->tap_res == res) return NLOS_OK;
+    std::vector<double> t;
+    if (kind == 1) host_taps_unit(t); else host_taps(refine, sigma_bin, res, t);
+    int rc = c->taps.ensure(t.size() * sizeof(double));
+    if (rc) return rc;
+    // synchronous upload (tiny; happens only when the tap parameters change)
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(c->taps.p, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->tap_kind = kind; c->tap_refine = refine; c->tap_sigma = sigma_bin; c->tap_res = res;
+    return NLOS_OK;
+}
+
+int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bool reuse, hipStream_t st) {
+    if (reuse && c->built_F == nF && c->built_V == nV) return NLOS_OK;
+    const size_t n_nodes = 2 * (size_t)nF - 1;
+    int rc = 0;
+    rc |= c->keys0.ensure(sizeof(uint32_t) * nF);
+    rc |= c->keys1.ensure(sizeof(uint32_t) * nF);
+    rc |= c->idx0.ensure(sizeof(int) * nF);
+    rc |= c->idx1.ensure(sizeof(int) * nF);
+    rc |= c->child.ensure(sizeof(int) * 2 * (size_t)nF);
+    rc |= c->range.ensure(sizeof(int) * 2 * (size_t)nF);
+    rc |= c->parent.ensure(sizeof(int) * n_nodes);
+    rc |= c->arrive.ensure(sizeof(int) * (size_t)nF);
+    rc |= c->box.ensure(sizeof(float) * 6 * n_nodes);
+    rc |= c->status.ensure(sizeof(int) * 4);
+    rc |= c->nodes.ensure(sizeof(float4) * 2 * n_nodes);
+    rc |= c->tris.ensure(sizeof(float4) * 3 * (size_t)nF);
+    rc |= c->facerec.ensure(sizeof(float4) * 4 * (size_t)nF);
+    rc |= c->face_id.ensure(sizeof(int) * (size_t)nF);
+    if (rc) return NLOS_ERR_HIP;
+    HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int) * 4, st));
+    nlos::BuildArgs b;
+    b.vertices = V; b.faces = F; b.V = nV; b.F = nF;
+    b.keys0 = c->keys0.as<uint32_t>(); b.keys1 = c->keys1.as<uint32_t>();
+    b.idx0 = c->idx0.as<int>(); b.idx1 = c->idx1.as<int>();
+    b.child = c->child.as<int>(); b.range = c->range.as<int>(); b.parent = c->parent.as<int>();
+    b.arrive = c->arrive.as<int>(); b.box = c->box.as<float>(); b.status = c->status.as<int>();
+    b.nodes = c->nodes.as<float4>(); b.tris = c->tris.as<float4>(); b.facerec = c->facerec.as<float4>();
+    b.face_id = c->face_id.as<int>();
+    nlos::launch_build_bvh(b, st);
+    HIP_TRY(hipGetLastError());
+    c->built_F = nF; c->built_V = nV;
+    return NLOS_OK;
+}
+
+nlos::SceneView scene_view(const nlos_ctx* c, int nF, int nV, const float* vn, const float* alb) {
+    nlos::SceneView s;
+    s.nodes = c->nodes.as<float4>(); s.tris = c->tris.as<float4>(); s.facerec = c->facerec.as<float4>();
+    s.face_id = c->face_id.as<int>();
+    s.n_nodes = 2 * nF - 1; s.F = nF; s.V = nV;
+    s.vertex_normal = vn; s.albedo = alb;
+    return s;
+}
+
+void mark(nlos_ctx* c, int i, hipStream_t st) {
+    if (c->timing) { hipError_t e = hipEventRecord(c->ev[i], st); (void)e; }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* nlos_last_error(void) { return g_err.c_str(); }
+
+int nlos_version(void) { return 100; }
+
+int nlos_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int nlos_num_bins(float lb, float ub, float res) {
+    // smoothed_transient/stratifiedStreamedGradientRenderer.cpp:514-515 (float32 ceil)
+    return (int)std::ceil((ub - lb) / res);
+}
+
+void nlos_set_default_seed(uint64_t seed) { g_default_seed = seed; }
+void nlos_set_default_device(int device) { g_default_device = device; }
+
+int nlos_ctx_create(int device, nlos_ctx** out) {
+    if (!out) return fail(NLOS_ERR_ARG, "nlos_ctx_create: out is NULL");
+    int n = nlos_device_count();
+    if (n <= 0) return fail(NLOS_ERR_NO_DEVICE, "no HIP device visible: libnlos_hip needs an AMD GPU (no CPU fallback)");
+    if (device < 0 || device >= n) return fail(NLOS_ERR_ARG, "nlos_ctx_create: bad device index");
+    nlos_ctx* c = new nlos_ctx();
+    c->device = device;
+    *out = c;
+    return NLOS_OK;
+}
+
+void nlos_ctx_destroy(nlos_ctx* c) {
+    if (!c) return;
+    DeviceGuard g(c->device);
+    DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
+                     &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->vis, &c->diff,
+                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp};
+    for (DevBuf* b : all) b->release();
+    for (DevBuf& b : c->io) b.release();
+    for (hipEvent_t& e : c->ev) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
+    delete c;
+}
+
+int64_t nlos_ctx_scratch_bytes(const nlos_ctx* c) {
+    if (!c) return 0;
+    const DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
+                           &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->vis, &c->diff,
+                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp};
+    int64_t s = 0;
+    for (const DevBuf* b : all) s += (int64_t)b->cap;
+    for (const DevBuf& b : c->io) s += (int64_t)b.cap;
+    return s;
+}
+
+void nlos_ctx_enable_timing(nlos_ctx* c, int enable) {
+    if (!c) return;
+    DeviceGuard g(c->device);
+    c->timing = enable != 0;
+    if (c->timing)
+        for (hipEvent_t& e : c->ev)
+            if (!e) { hipError_t r = hipEventCreate(&e); (void)r; }
+}
+
+int nlos_ctx_last_timing(nlos_ctx* c, float* ms4) {
+    if (!c || !ms4) return fail(NLOS_ERR_ARG, "nlos_ctx_last_timing: NULL argument");
+    if (!c->timing || !c->ev_valid) return fail(NLOS_ERR_ARG, "timing not enabled or no render recorded");
+    DeviceGuard g(c->device);
+    for (int i = 0; i < 4; ++i) {
+        ms4[i] = 0.0f;
+        hipError_t e = hipEventElapsedTime(&ms4[i], c->ev[i], c->ev[i + 1]);
+        if (e != hipSuccess) return fail(NLOS_ERR_HIP, std::string("hipEventElapsedTime: ") + hipGetErrorString(e));
+    }
+    return NLOS_OK;
+}
+
+void nlos_render_args_init(nlos_render_args* a) {
+    if (!a) return;
+    std::memset(a, 0, sizeof(*a));
+    a->refine_scale = 1;
+    a->sigma_bin = 1;
+    a->normal_term = -1;
+    a->clamp = 1;
+    a->vertex_num = -1;
+}
+
+int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
+    if (!c || !a) return fail(NLOS_ERR_ARG, "nlos_render: NULL ctx/args");
+    if (a->F <= 0 || a->V <= 0) return fail(NLOS_ERR_ARG, "nlos_render: empty mesh");
+    if (a->L < 0) return fail(NLOS_ERR_ARG, "nlos_render: negative source count");
+    if (!a->vertices || !a->faces) return fail(NLOS_ERR_ARG, "nlos_render: vertices/faces are NULL");
+    if (a->L > 0 && (!a->origin || !a->normal)) return fail(NLOS_ERR_ARG, "nlos_render: origin/normal are NULL");
+    if (a->num_samples <= 0) return fail(NLOS_ERR_ARG, "nlos_render: num_samples must be positive");
+    if (!(a->resolution > 0.0f) || !(a->upper_bound > a->lower_bound) )
+        if (a->mode != NLOS_MODE_INTENSITY) return fail(NLOS_ERR_ARG, "nlos_render: need resolution > 0 and upper_bound > lower_bound");
+    if (a->refine_scale < 1 || a->sigma_bin < 1) return fail(NLOS_ERR_ARG, "nlos_render: refine_scale and sigma_bin must be >= 1");
+    const int mode = a->mode;
+    const bool needs_grad = mode == NLOS_MODE_GRADIENT || mode == NLOS_MODE_GRAD_ALBEDO || mode == NLOS_MODE_GRAD_ALPHA ||
+                            mode == NLOS_MODE_GRADIENT_V1;
+    if (needs_grad && !a->residual && (!a->data || !a->transient))
+        return fail(NLOS_ERR_ARG, "nlos_render: gradient modes need data and transient (or residual)");
+    if (a->residual && mode != NLOS_MODE_GRADIENT) return fail(NLOS_ERR_ARG, "nlos_render: residual is only valid in GRADIENT mode");
+    if (a->reuse_visibility && !a->residual) return fail(NLOS_ERR_ARG, "nlos_render: reuse_visibility needs residual");
+    if ((mode == NLOS_MODE_GRADIENT || mode == NLOS_MODE_GRADIENT_V1 || mode == NLOS_MODE_VERTEX_GRADIENT) && !a->gradient)
+        return fail(NLOS_ERR_ARG, "nlos_render: gradient output is NULL");
+    if ((mode == NLOS_MODE_GRAD_ALBEDO || mode == NLOS_MODE_GRAD_ALPHA) && !a->scalar_out)
+        return fail(NLOS_ERR_ARG, "nlos_render: scalar_out is NULL");
+    if (mode == NLOS_MODE_TRANSIENT && !a->transient) return fail(NLOS_ERR_ARG, "nlos_render: transient is NULL");
+    if (mode == NLOS_MODE_INTENSITY && !a->intensity) return fail(NLOS_ERR_ARG, "nlos_render: intensity is NULL");
+    if (mode < 0 || mode > NLOS_MODE_GRADIENT_V1) return fail(NLOS_ERR_ARG, "nlos_render: unknown mode");
+    if (mode == NLOS_MODE_VERTEX_GRADIENT && (a->vertex_num < 0 || a->vertex_num >= a->V))
+        return fail(NLOS_ERR_ARG, "nlos_render: vertex_num out of range");
+
+    DeviceGuard guard(c->device);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int L = a->L, nF = a->F, nV = a->V;
+    const float lb = a->lower_bound, ub = a->upper_bound, res = a->resolution;
+    const int T = mode == NLOS_MODE_INTENSITY ? 1 : nlos_num_bins(lb, ub, res);
+    if (T <= 0) return fail(NLOS_ERR_ARG, "nlos_render: zero bins");
+    const int spt = 1 + ((a->num_samples - 1) / nF);
+    const int vis_words = (spt + 31) / 32;
+
+    mark(c, 0, st);
+    int rc = ensure_bvh(c, a->vertices, nV, a->faces, nF, a->reuse_bvh != 0, st);
+    if (rc) return rc;
+    mark(c, 1, st);
+
+    nlos::SourceView src;
+    src.origin = a->origin; src.normal = a->normal; src.L = L;
+    src.source_offset = a->source_offset; src.total_sources = a->total_sources;
+
+    nlos::SampleParams sp;
+    sp.seed = a->seed; sp.spt = spt; sp.lb = lb; sp.ub = ub;
+    sp.clamp = a->clamp; sp.use_ggx = a->use_ggx; sp.ggx_alpha = a->ggx_alpha;
+
+    const float* vn = a->vertex_normal;
+    const float* alb = a->albedo;
+    if (mode == NLOS_MODE_VERTEX_GRADIENT || mode == NLOS_MODE_GRADIENT_V1) { vn = nullptr; alb = nullptr; sp.use_ggx = 0; }
+    if (mode == NLOS_MODE_GRAD_ALBEDO) { vn = nullptr; sp.use_ggx = 0; }
+    if (mode == NLOS_MODE_GRAD_ALPHA) { sp.use_ggx = 1; }
+    if (mode == NLOS_MODE_GRADIENT_V1) sp.clamp = 1;
+    nlos::SceneView sc = scene_view(c, nF, nV, vn, alb);
+
+    // ---- pass 1 -------------------------------------------------------------------
+    const bool two_pass = mode != NLOS_MODE_TRANSIENT && mode != NLOS_MODE_INTENSITY;
+    int fwd_refine = a->refine_scale;
+    // smoothed_transient/stratifiedStreamedGradientRenderer.cpp:521-524
+    if (two_pass) fwd_refine = a->sigma_bin < 5 ? 1 : a->refine_scale;
+    if (mode == NLOS_MODE_GRADIENT_V1 || mode == NLOS_MODE_INTENSITY) fwd_refine = 1;
+    const int rb = T * fwd_refine;
+
+    nlos::ForwardArgs fa;
+    fa.sc = sc; fa.src = src; fa.sp = sp;
+    fa.sp.res = fwd_refine > 1 ? res / fwd_refine : res;
+    fa.sp.nbins = rb;
+    fa.vis = nullptr; fa.vis_words = vis_words;
+    fa.intensity = a->intensity; fa.mode_intensity = mode == NLOS_MODE_INTENSITY ? 1 : 0;
+    fa.rows = nullptr;
+    nlos_ctx::VisKey key;
+    key.L = L; key.F = nF; key.V = nV; key.spt = spt; key.off = a->source_offset; key.seed = a->seed;
+    key.lb = lb; key.ub = ub;
+    key.feat = (vn ? 1 : 0) | (alb ? 2 : 0) | (sp.use_ggx ? 4 : 0) | (sp.clamp ? 8 : 0);
+    const bool skip_pass1 = a->reuse_visibility != 0;
+    if (skip_pass1) {
+        const nlos_ctx::VisKey& k = c->vis_key;
+        if (!(k.L == key.L && k.F == key.F && k.V == key.V && k.spt == key.spt && k.off == key.off && k.seed == key.seed &&
+              k.lb == key.lb && k.ub == key.ub && k.feat == key.feat))
+            return fail(NLOS_ERR_ARG, "nlos_render: reuse_visibility requested but the cache does not match this render");
+    }
+    if (two_pass || a->keep_visibility) {
+        rc = c->vis.ensure(sizeof(uint32_t) * (size_t)L * vis_words * nF + 16);
+        if (rc) return rc;
+        fa.vis = c->vis.as<uint32_t>();
+        c->vis_key = key;
+    } else {
+        c->vis_key = nlos_ctx::VisKey();
+    }
+    double* transient = a->transient;
+    if (mode == NLOS_MODE_GRADIENT && a->residual && !transient) {
+        rc = c->rows_tmp.ensure(sizeof(double) * (size_t)L * T + 16);
+        if (rc) return rc;
+        transient = c->rows_tmp.as<double>();
+    }
+    if (mode == NLOS_MODE_VERTEX_GRADIENT && !transient) {
+        rc = c->rows_tmp.ensure(sizeof(double) * (size_t)L * T + 16);
+        if (rc) return rc;
+        transient = c->rows_tmp.as<double>();
+    }
+    if (mode != NLOS_MODE_INTENSITY) {
+        if (fwd_refine > 1) {
+            rc = c->fine.ensure(sizeof(double) * (size_t)L * rb + 16);
+            if (rc) return rc;
+            fa.rows = c->fine.as<double>();
+        } else {
+            fa.rows = transient;
+        }
+    }
+    if (!skip_pass1) nlos::launch_forward(fa, st);
+    if (!skip_pass1 && mode != NLOS_MODE_INTENSITY && fwd_refine > 1) {
+        // Gaussian of the refined histogram (row FD): kernel = the gradient taps' w
+        int K = 0;
+        rc = ensure_taps(c, 0, fwd_refine, a->sigma_bin, res, st, &K);
+        if (rc) return rc;
+        nlos::SmoothArgs sm;
+        sm.fine = c->fine.as<double>(); sm.transient = transient; sm.kernel = c->taps.as<double>();
+        sm.L = L; sm.T = T; sm.refine = fwd_refine; sm.sigma_bin = a->sigma_bin; sm.K = K;
+        nlos::launch_smooth(sm, st);
+    }
+    mark(c, 2, st);
+
+    // ---- residual + pathlengths -----------------------------------------------------
+    if (mode == NLOS_MODE_TRANSIENT || (mode == NLOS_MODE_VERTEX_GRADIENT)) {
+        if (a->pathlengths) {
+            nlos::ResidualArgs ra;
+            std::memset(&ra, 0, sizeof(ra));
+            ra.pathlengths = a->pathlengths; ra.L = 0; ra.T = T; ra.lb = lb; ra.res = res;
+            nlos::launch_residual(ra, st);
+        }
+    }
+    const double* diff_ptr = a->residual;
+    if (needs_grad && a->residual && a->pathlengths) {
+        nlos::ResidualArgs ra;
+        std::memset(&ra, 0, sizeof(ra));
+        ra.pathlengths = a->pathlengths; ra.L = 0; ra.T = T; ra.lb = lb; ra.res = res;
+        nlos::launch_residual(ra, st);
+    }
+    if (needs_grad && !a->residual) {
+        rc = c->diff.ensure(sizeof(double) * (size_t)L * T + 16);
+        if (rc) return rc;
+        nlos::ResidualArgs ra;
+        ra.data = a->data; ra.weight = mode == NLOS_MODE_GRADIENT_V1 ? nullptr : a->weight;
+        ra.transient = transient; ra.diff = c->diff.as<double>();
+        ra.pathlengths = a->pathlengths; ra.L = L; ra.T = T;
+        ra.loss_test = mode == NLOS_MODE_GRADIENT_V1 ? 0 : a->loss_test;
+        ra.lb = lb; ra.res = res;
+        ra.w_width = mode == NLOS_MODE_GRADIENT_V1 ? a->w_width : 0;
+        nlos::launch_residual(ra, st);
+        diff_ptr = c->diff.as<double>();
+    }
+    mark(c, 3, st);
+
+    // ---- pass 2 -----------------------------------------------------------------------
+    if (two_pass) {
+        int K = 0;
+        rc = ensure_taps(c, mode == NLOS_MODE_GRADIENT_V1 ? 1 : 0, a->refine_scale, a->sigma_bin, res, st, &K);
+        if (rc) return rc;
+        nlos::GradientArgs ga;
+        ga.sc = sc; ga.src = src; ga.sp = sp;
+        ga.sp.res = res; ga.sp.nbins = T;
+        ga.vis = c->vis.as<uint32_t>(); ga.vis_words = vis_words;
+        ga.tap_w = c->taps.as<double>(); ga.tap_delta = ga.tap_w + K; ga.tap_g = ga.tap_w + 2 * K;
+        ga.K = K;
+        ga.v1_style = mode == NLOS_MODE_GRADIENT_V1 ? 1 : 0;
+        ga.vertex_num = a->vertex_num;
+        ga.diff = diff_ptr;
+        switch (mode) {
+            case NLOS_MODE_GRADIENT:
+                ga.mode = 0;
+                ga.normal_term = a->normal_term < 0 ? ((a->testing_flag == 0 && vn != nullptr) ? 1 : 0) : (a->normal_term ? 1 : 0);
+                ga.out = a->gradient;
+                break;
+            case NLOS_MODE_GRADIENT_V1:
+                ga.mode = 0; ga.normal_term = 1; ga.out = a->gradient;
+                // v1 zeroes the output (stratified_transient_raytracer/stratifiedStreamedGradientRenderer.cpp:419)
+                nlos::launch_zero_f64(a->gradient, 3 * (size_t)nV, st);
+                break;
+            case NLOS_MODE_GRAD_ALBEDO:
+                ga.mode = 1; ga.normal_term = 0; ga.out = a->scalar_out;
+                nlos::launch_zero_f64(a->scalar_out, 1, st);
+                break;
+            case NLOS_MODE_GRAD_ALPHA:
+                ga.mode = 2; ga.normal_term = 0; ga.out = a->scalar_out;
+                nlos::launch_zero_f64(a->scalar_out, 1, st);
+                break;
+            default:  // NLOS_MODE_VERTEX_GRADIENT
+                ga.mode = 3; ga.normal_term = 1; ga.out = a->gradient;
+                ga.diff = transient;   // unused by mode 3; any valid [L,T] buffer
+                break;
+        }
+        ga.lds_grad = (ga.mode == 0 && 3 * (size_t)nV * sizeof(double) + (size_t)T * sizeof(double) + 64 <= (size_t)nlos::kGradLdsBudget) ? 1 : 0;
+        nlos::launch_gradient(ga, st);
+    }
+    mark(c, 4, st);
+    c->ev_valid = c->timing;
+    HIP_TRY(hipGetLastError());
+    return NLOS_OK;
+}
+
+int nlos_intersect(nlos_ctx* c, const float* origins, const float* dirs, int n_rays, const float* vertices, int V,
+                   const int32_t* faces, int F, float* out3, float* out1, void* stream) {
+    if (!c) return fail(NLOS_ERR_ARG, "nlos_intersect: NULL ctx");
+    if (F <= 0 || V <= 0 || !vertices || !faces) return fail(NLOS_ERR_ARG, "nlos_intersect: empty mesh");
+    if (n_rays < 0 || (n_rays > 0 && (!origins || !dirs))) return fail(NLOS_ERR_ARG, "nlos_intersect: bad rays");
+    DeviceGuard guard(c->device);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc = ensure_bvh(c, vertices, V, faces, F, false, st);
+    if (rc) return rc;
+    nlos::IntersectArgs ia;
+    ia.sc = scene_view(c, F, V, nullptr, nullptr);
+    ia.origins = origins; ia.dirs = dirs; ia.n = n_rays; ia.out3 = out3; ia.out1 = out1;
+    nlos::launch_intersect(ia, st);
+    HIP_TRY(hipGetLastError());
+    return NLOS_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================
+// Section 1: host-pointer drop-ins.  Upload -> nlos_render -> download, synchronous.
+// =====================================================================================
+namespace {
+
+struct HostCall {
+    nlos_ctx* c = nullptr;
+    int slot = 0;
+    int rc = NLOS_OK;
+    std::vector<std::pair<void*, std::pair<void*, size_t>>> downloads;  // host <- dev
+
+    template <class T>
+    T* up(const T* host, size_t count) {
+        if (rc || !host || count == 0) return nullptr;
+        DevBuf& b = c->io[slot++];
+        rc = b.ensure(count * sizeof(T));
+        if (rc) return nullptr;
+        hipError_t e = hipMemcpy(b.p, host, count * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { rc = fail(NLOS_ERR_HIP, std::string("hipMemcpy H2D: ") + hipGetErrorString(e)); return nullptr; }
+        return b.as<T>();
+    }
+    template <class T>
+    T* inout(T* host, size_t count, bool upload) {
+        if (rc || !host || count == 0) return nullptr;
+        DevBuf& b = c->io[slot++];
+        rc = b.ensure(count * sizeof(T));
+        if (rc) return nullptr;
+        if (upload) {
+            hipError_t e = hipMemcpy(b.p, host, count * sizeof(T), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { rc = fail(NLOS_ERR_HIP, std::string("hipMemcpy H2D: ") + hipGetErrorString(e)); return nullptr; }
+        }
+        downloads.push_back({host, {b.p, count * sizeof(T)}});
+        return b.as<T>();
+    }
+    int finish() {
+        if (rc) return rc;
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) return fail(NLOS_ERR_HIP, std::string("hipDeviceSynchronize: ") + hipGetErrorString(e));
+        for (auto& d : downloads) {
+            e = hipMemcpy(d.first, d.second.first, d.second.second, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return fail(NLOS_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
+        }
+        int st[4] = {0, 0, 0, 0};
+        e = hipMemcpy(st, c->status.p, sizeof(st), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && (st[0] & 1)) return fail(NLOS_ERR_ARG, "face index out of range [0, numVertices)");
+        return NLOS_OK;
+    }
+};
+
+struct HostRender {
+    int mode = NLOS_MODE_TRANSIENT;
+    double *data = nullptr, *weight = nullptr;
+    float *origin = nullptr, *normal = nullptr, *vertices = nullptr, *vnormal = nullptr, *albedo = nullptr;
+    int* faces = nullptr;
+    int L = 0, V = 0, F = 0, num_samples = 0;
+    float lb = 0, ub = 0, res = 1;
+    double *transient = nullptr, *pathlengths = nullptr, *gradient = nullptr, *intensity = nullptr, *scalar = nullptr;
+    int refine = 1, sigma_bin = 1, testing_flag = 0, loss_test = 0, use_ggx = 0, clamp = 1, w_width = 0, vertex_num = -1;
+    float alpha = 0;
+};
+
+int host_render(const HostRender& h) {
+    if (h.F <= 0 || h.V <= 0 || !h.vertices || !h.faces) return fail(NLOS_ERR_ARG, "empty mesh");
+    if (h.L < 0) return fail(NLOS_ERR_ARG, "negative source count");
+    for (size_t i = 0; i < 3 * (size_t)h.F; ++i)
+        if (h.faces[i] < 0 || h.faces[i] >= h.V) return fail(NLOS_ERR_ARG, "face index out of range [0, numVertices)");
+    nlos_ctx* c = nullptr;
+    int rc = get_default_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceGuard guard(c->device);
+    HostCall hc;
+    hc.c = c;
+    const int T = h.mode == NLOS_MODE_INTENSITY ? 0 : nlos_num_bins(h.lb, h.ub, h.res);
+    nlos_render_args a;
+    nlos_render_args_init(&a);
+    a.mode = h.mode;
+    a.origin = hc.up(h.origin, 3 * (size_t)h.L);
+    a.normal = hc.up(h.normal, 3 * (size_t)h.L);
+    a.L = h.L; a.source_offset = 0; a.total_sources = h.L;
+    a.vertices = hc.up(h.vertices, 3 * (size_t)h.V); a.V = h.V;
+    a.faces = hc.up(h.faces, 3 * (size_t)h.F); a.F = h.F;
+    a.vertex_normal = hc.up(h.vnormal, 3 * (size_t)h.V);
+    a.albedo = hc.up(h.albedo, (size_t)h.V);
+    a.num_samples = h.num_samples;
+    a.lower_bound = h.lb; a.upper_bound = h.ub; a.resolution = h.res;
+    a.refine_scale = h.refine; a.sigma_bin = h.sigma_bin;
+    a.seed = g_default_seed;
+    a.data = hc.up(h.data, (size_t)h.L * T);
+    a.weight = hc.up(h.weight, (size_t)h.L * T);
+    a.transient = hc.inout(h.transient, (size_t)h.L * T, false);
+    a.pathlengths = hc.inout(h.pathlengths, (size_t)T, false);
+    if (h.mode == NLOS_MODE_VERTEX_GRADIENT) a.gradient = hc.inout(h.gradient, 3 * (size_t)T, true);
+    else a.gradient = hc.inout(h.gradient, 3 * (size_t)h.V, h.mode != NLOS_MODE_GRADIENT_V1);
+    a.intensity = hc.inout(h.intensity, (size_t)h.F, true);
+    a.scalar_out = hc.inout(h.scalar, 1, false);
+    a.testing_flag = h.testing_flag; a.loss_test = h.loss_test;
+    a.normal_term = -1; a.clamp = h.clamp; a.use_ggx = h.use_ggx; a.ggx_alpha = h.alpha;
+    a.vertex_num = h.vertex_num; a.w_width = h.w_width;
+    if (hc.rc) return hc.rc;
+    if (h.L == 0) {
+        // nothing to render: outputs keep the reference's semantics (transient is [0,T])
+        if (h.pathlengths) for (int i = 0; i < T; ++i) h.pathlengths[i] = (double)(h.lb + i * h.res);
+        if (h.scalar) *h.scalar = 0.0;
+        return NLOS_OK;
+    }
+    rc = nlos_render(c, &a, nullptr);
+    if (rc) return rc;
+    return hc.finish();
+}
+
+}  // namespace
+
+extern "C" {
+
+int nlos_streamed_render_transient(float* origin, int numSources, float* normal, float* vertices, int numVertices,
+                                   float* vertexNormal, float* vertexAlbedo, int* triangles, int numTriangles,
+                                   int numSamples, float lowerBound, float upperBound, float resolution,
+                                   double* transient, double* pathlengths, int refine_scale, int sigma_bin) {
+    HostRender h;
+    h.mode = NLOS_MODE_TRANSIENT;
+    h.origin = origin; h.L = numSources; h.normal = normal; h.vertices = vertices; h.V = numVertices;
+    h.vnormal = vertexNormal; h.albedo = vertexAlbedo; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.transient = transient; h.pathlengths = pathlengths; h.refine = refine_scale; h.sigma_bin = sigma_bin;
+    return host_render(h);
+}
+
+int nlos_streamed_render_intensity(float* origin, int numSources, float* normal, float* vertices, int numVertices,
+                                   float* vertexNormal, int* triangles, int numTriangles, int numSamples,
+                                   float lowerBound, float upperBound, double* intensity) {
+    HostRender h;
+    h.mode = NLOS_MODE_INTENSITY;
+    h.origin = origin; h.L = numSources; h.normal = normal; h.vertices = vertices; h.V = numVertices;
+    h.vnormal = vertexNormal; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = 1.0f;
+    h.intensity = intensity;
+    return host_render(h);
+}
+
+int nlos_streamed_render_gradient(double* data, double* weight, float* origin, int measurement, float* normal,
+                                  float* vertices, int numVertices, float* vertexNormal, int* triangles,
+                                  int numTriangles, int numSamples, float lowerBound, float upperBound,
+                                  float resolution, double* transient, double* pathlengths, double* gradient,
+                                  int refine_scale, int sigma_bin, int testing_flag, int loss_test) {
+    HostRender h;
+    h.mode = NLOS_MODE_GRADIENT;
+    h.data = data; h.weight = weight;
+    h.origin = origin; h.L = measurement; h.normal = normal; h.vertices = vertices; h.V = numVertices;
+    h.vnormal = vertexNormal; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.transient = transient; h.pathlengths = pathlengths; h.gradient = gradient;
+    h.refine = refine_scale; h.sigma_bin = sigma_bin; h.testing_flag = testing_flag; h.loss_test = loss_test;
+    return host_render(h);
+}
+
+int nlos_streamed_render_gradient_w_albedo(double* data, double* weight, float* origin, int measurement,
+                                           float* normal, float* vertices, int numVertices, float* albedo,
+                                           int* triangles, int numTriangles, int numSamples, float lowerBound,
+                                           float upperBound, float resolution, double* transient,
+                                           double* pathlengths, double* gradient, int refine_scale, int sigma_bin,
+                                           int testing_flag, int loss_test) {
+    HostRender h;
+    h.mode = NLOS_MODE_GRADIENT;
+    h.data = data; h.weight = weight;
+    h.origin = origin; h.L = measurement; h.normal = normal; h.vertices = vertices; h.V = numVertices;
+    h.albedo = albedo; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.transient = transient; h.pathlengths = pathlengths; h.gradient = gradient;
+    h.refine = refine_scale; h.sigma_bin = sigma_bin; h.testing_flag = testing_flag; h.loss_test = loss_test;
+    return host_render(h);
+}
+
+int nlos_streamed_render_gradient_albedo(double* data, double* weight, float* origin, int measurement, float* normal,
+                                         float* vertices, int numVertices, float* albedo, int* triangles,
+                                         int numTriangles, int numSamples, float lowerBound, float upperBound,
+                                         float resolution, double* transient, double* pathlengths, int refine_scale,
+                                         int sigma_bin, int testing_flag, int loss_test, double* grad_out) {
+    HostRender h;
+    h.mode = NLOS_MODE_GRAD_ALBEDO;
+    h.data = data; h.weight = weight;
+    h.origin = origin; h.L = measurement; h.normal = normal; h.vertices = vertices; h.V = numVertices;
+    h.albedo = albedo; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.transient = transient; h.pathlengths = pathlengths; h.scalar = grad_out;
+    h.refine = refine_scale; h.sigma_bin = sigma_bin; h.testing_flag = testing_flag; h.loss_test = loss_test;
+    return host_render(h);
+}
+
+int nlos_streamed_render_vertex_gradient(int vertex_num, float* origin, int measurement, float* normal,
+                                         float* vertices, int numVertices, int* triangles, int numTriangles,
+                                         int numSamples, float lowerBound, float upperBound, float resolution,
+                                         double* gradient, int refine_scale, int sigma_bin) {
+    HostRender h;
+    h.mode = NLOS_MODE_VERTEX_GRADIENT;
+    h.origin = origin; h.L = measurement; h.normal = normal; h.vertices = vertices; h.V = numVertices;
+    h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.gradient = gradient; h.refine = refine_scale; h.sigma_bin = sigma_bin; h.vertex_num = vertex_num;
+    return host_render(h);
+}
+
+int nlos_ggx_streamed_render_transient(float* origin, int numSources, float* normal, float* vertices,
+                                       int numVertices, float* vertexNormal, float* vertexAlbedo, int* triangles,
+                                       int numTriangles, float alpha, int numSamples, float lowerBound,
+                                       float upperBound, float resolution, double* transient, double* pathlengths,
+                                       int refine_scale, int sigma_bin) {
+    HostRender h;
+    h.mode = NLOS_MODE_TRANSIENT; h.use_ggx = 1; h.alpha = alpha;
+    h.origin = origin; h.L = numSources; h.normal = normal; h.vertices = vertices; h.V = numVertices;
+    h.vnormal = vertexNormal; h.albedo = vertexAlbedo; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.transient = transient; h.pathlengths = pathlengths; h.refine = refine_scale; h.sigma_bin = sigma_bin;
+    return host_render(h);
+}
+
+int nlos_ggx_streamed_render_intensity(float* origin, int numSources, float* normal, float* vertices,
+                                       int numVertices, float* vertexNormal, int* triangles, int numTriangles,
+                                       float alpha, int numSamples, float lowerBound, float upperBound,
+                                       double* intensity) {
+    HostRender h;
+    h.mode = NLOS_MODE_INTENSITY; h.use_ggx = 1; h.alpha = alpha;
+    h.origin = origin; h.L = numSources; h.normal = normal; h.vertices = vertices; h.V = numVertices;
+    h.vnormal = vertexNormal; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = 1.0f;
+    h.intensity = intensity;
+    return host_render(h);
+}
+
+int nlos_ggx_streamed_render_gradient(double* data, double* weight, float* origin, int measurement, float* normal,
+                                      float* vertices, int numVertices, float* vertexNormal, int* triangles,
+                                      int numTriangles, float alpha, int numSamples, float lowerBound,
+                                      float upperBound, float resolution, double* transient, double* pathlengths,
+                                      double* gradient, int refine_scale, int sigma_bin, int testing_flag) {
+    HostRender h;
+    h.mode = NLOS_MODE_GRADIENT; h.use_ggx = 1; h.alpha = alpha;
+    h.data = data; h.weight = weight;
+    h.origin = origin; h.L = measurement; h.normal = normal; h.vertices = vertices; h.V = numVertices;
+    h.vnormal = vertexNormal; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.transient = transient; h.pathlengths = pathlengths; h.gradient = gradient;
+    h.refine = refine_scale; h.sigma_bin = sigma_bin; h.testing_flag = testing_flag; h.loss_test = 0;
+    return host_render(h);
+}
+
+int nlos_ggx_streamed_render_gradient_alpha(double* data, double* weight, float* origin, int measurement,
+                                            float* normal, float* vertices, int numVertices, float* vertexNormal,
+                                            int* triangles, int numTriangles, float alpha, int numSamples,
+                                            float lowerBound, float upperBound, float resolution, double* transient,
+                                            double* pathlengths, int refine_scale, int sigma_bin, double* grad_out) {
+    HostRender h;
+    h.mode = NLOS_MODE_GRAD_ALPHA; h.use_ggx = 1; h.alpha = alpha;
+    h.data = data; h.weight = weight;
+    h.origin = origin; h.L = measurement; h.normal = normal; h.vertices = vertices; h.V = numVertices;
+    h.vnormal = vertexNormal; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.transient = transient; h.pathlengths = pathlengths; h.scalar = grad_out;
+    h.refine = refine_scale; h.sigma_bin = sigma_bin;
+    return host_render(h);
+}
+
+int nlos_v1_streamed_render_gradient(double* data, float* origin, int measurement, float* normal, float* vertices,
+                                     int numVertices, int* triangles, int numTriangles, int numSamples,
+                                     float lowerBound, float upperBound, float resolution, int w_width,
+                                     double* transient, double* pathlengths, double* gradient) {
+    HostRender h;
+    h.mode = NLOS_MODE_GRADIENT_V1;
+    h.data = data;
+    h.origin = origin; h.L = measurement; h.normal = normal; h.vertices = vertices; h.V = numVertices;
+    h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.transient = transient; h.pathlengths = pathlengths; h.gradient = gradient; h.w_width = w_width;
+    return host_render(h);
+}
+
+int nlos_v1_streamed_render_transient(float* origin, int numSources, float* normal, float* vertices, int numVertices,
+                                      float* vertexNormal, float* vertexAlbedo, int* triangles, int numTriangles,
+                                      int numSamples, float lowerBound, float upperBound, float resolution,
+                                      double* transient, double* pathlengths) {
+    HostRender h;
+    h.mode = NLOS_MODE_TRANSIENT; h.clamp = 0;
+    h.origin = origin; h.L = numSources; h.normal = normal; h.vertices = vertices; h.V = numVertices;
+    h.vnormal = vertexNormal; h.albedo = vertexAlbedo; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.transient = transient; h.pathlengths = pathlengths;
+    return host_render(h);
+}
+
+static int host_intersect(float* origins, float* directions, int num_ray, float* vertices, int num_vertices,
+                          int* triangles, int num_triangles, float* out, bool shortform) {
+    if (num_triangles <= 0 || num_vertices <= 0 || !vertices || !triangles) return fail(NLOS_ERR_ARG, "empty mesh");
+    if (num_ray < 0) return fail(NLOS_ERR_ARG, "negative ray count");
+    if (num_ray == 0) return NLOS_OK;
+    if (!origins || !directions || !out) return fail(NLOS_ERR_ARG, "NULL ray buffers");
+    for (size_t i = 0; i < 3 * (size_t)num_triangles; ++i)
+        if (triangles[i] < 0 || triangles[i] >= num_vertices) return fail(NLOS_ERR_ARG, "face index out of range [0, numVertices)");
+    nlos_ctx* c = nullptr;
+    int rc = get_default_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceGuard guard(c->device);
+    HostCall hc;
+    hc.c = c;
+    const float* o = hc.up(origins, 3 * (size_t)num_ray);
+    const float* d = hc.up(directions, 3 * (size_t)num_ray);
+    const float* v = hc.up(vertices, 3 * (size_t)num_vertices);
+    const int* f = hc.up(triangles, 3 * (size_t)num_triangles);
+    // [N,3] output keeps the caller's u,v on a miss (c_embree_intersector.cpp:39-45): upload it first
+    float* r = hc.inout(out, shortform ? (size_t)num_ray : 3 * (size_t)num_ray, !shortform);
+    if (hc.rc) return hc.rc;
+    rc = nlos_intersect(c, o, d, num_ray, v, num_vertices, f, num_triangles, shortform ? nullptr : r,
+                        shortform ? r : nullptr, nullptr);
+    if (rc) return rc;
+    return hc.finish();
+}
+
+int nlos_embree3_tbb_line_intersection(float* origins, float* directions, int num_ray, float* vertices,
+                                       int num_vertices, int* triangles, int num_triangles, float* intersect) {
+    return host_intersect(origins, directions, num_ray, vertices, num_vertices, triangles, num_triangles, intersect, false);
+}
+
+int nlos_embree3_tbb_short_line_intersection(float* origins, float* directions, int num_ray, float* vertices,
+                                             int num_vertices, int* triangles, int num_triangles, float* intersect) {
+    return host_intersect(origins, directions, num_ray, vertices, num_vertices, triangles, num_triangles, intersect, true);
+}
+
+int nlos_barycentric_to_world_n(float* vertices, int num_vertices, int* triangles, int num_triangles,
+                                float* barycoord, int num_ray, float* intersection_p) {
+    if (num_ray < 0 || num_vertices <= 0 || num_triangles <= 0 || !vertices || !triangles ||
+        (num_ray > 0 && (!barycoord || !intersection_p)))
+        return fail(NLOS_ERR_ARG, "nlos_barycentric_to_world: bad arguments");
+    if (num_ray == 0) return NLOS_OK;
+    nlos_ctx* c = nullptr;
+    int rc = get_default_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceGuard guard(c->device);
+    HostCall hc;
+    hc.c = c;
+    const float* v = hc.up(vertices, 3 * (size_t)num_vertices);
+    const int* f = hc.up(triangles, 3 * (size_t)num_triangles);
+    const float* b = hc.up(barycoord, 3 * (size_t)num_ray);
+    // rows whose face id is negative keep the caller's values (c_embree_intersector.cpp:79-80)
+    float* out = hc.inout(intersection_p, 3 * (size_t)num_ray, true);
+    if (hc.rc) return hc.rc;
+    nlos::launch_bary_to_world(v, f, b, num_ray, out, nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NLOS_ERR_HIP, std::string("bary_to_world launch: ") + hipGetErrorString(e));
+    hipError_t e2 = hipDeviceSynchronize();
+    if (e2 != hipSuccess) return fail(NLOS_ERR_HIP, std::string("hipDeviceSynchronize: ") + hipGetErrorString(e2));
+    for (auto& d : hc.downloads) {
+        e = hipMemcpy(d.first, d.second.first, d.second.second, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return fail(NLOS_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
+    }
+    return NLOS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,266 @@
+// nlos_device.h -- device-side numeric contract of the gfx950 transient renderer.
+//
+// Everything that decides accept/reject of a surface sample is plain IEEE fp32
+// evaluated in a fixed order (this translation unit is built with
+// -ffp-contract=off; correctly rounded sqrt/div are hipcc defaults), so the HIP
+// kernels and the independent CPU oracle make bit-identical visibility decisions:
+//   dot(a,b)   = (a.x*b.x + a.y*b.y) + a.z*b.z
+//   cross(a,b) = (a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x)
+//   u*A+v*B+w*C = ((u*A) + (v*B)) + (w*C)
+// Reference behaviour restated here (paths relative to transient_rendering_cython/):
+//   sample map            smoothed_transient/transient_and_gradient.cpp:178-196
+//   float from random bits stratified_transient_raytracer/rng_sse.h:33-42
+//   triangle test         Embree 3 Moeller-Trumbore (published algorithm), rows I/E
+//   GGX                   ggx/ggx_confocal.cpp:13-232
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nlos {
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ V3 bary(float u, V3 a, float v, V3 b, float w, V3 c) {
+    return ((a * u) + (b * v)) + (c * w);
+}
+__device__ __forceinline__ V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
+
+// ---------------------------------------------------------------- RNG (row R)
+// k-th output of splitmix64 seeded with `seed`; S from the low, T from the high
+// 32 bits; 23-bit mantissa floats in [0,1).  k = ((l*F + f)*spt + s) with the
+// GLOBAL source index l and the ORIGINAL face index f, so results do not depend
+// on source sharding or on the BVH's face ordering.
+__device__ __forceinline__ float u32_to_unit(uint32_t x) {
+    return __uint_as_float((x >> 9) | 0x3f800000u) - 1.0f;
+}
+__device__ __forceinline__ void sample_st(uint64_t seed, uint64_t k, float& S, float& T) {
+    uint64_t z = seed + (k + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    S = u32_to_unit((uint32_t)(z & 0xffffffffull));
+    T = u32_to_unit((uint32_t)(z >> 32));
+}
+
+// ------------------------------------------------------------ triangle record
+// 48-byte record, sorted (Morton) order: p0, e1 = p0-p1, e2 = p2-p0, ng = e2 x e1
+struct Tri { V3 p0, e1, e2, ng; };
+
+__device__ __forceinline__ Tri make_tri(V3 p0, V3 p1, V3 p2) {
+    Tri t;
+    t.p0 = p0;
+    t.e1 = p0 - p1;
+    t.e2 = p2 - p0;
+    t.ng = cross(t.e2, t.e1);
+    return t;
+}
+
+__device__ __forceinline__ Tri load_tri(const float4* __restrict__ tris, int j) {
+    float4 a = tris[3 * j], b = tris[3 * j + 1], c = tris[3 * j + 2];
+    Tri t;
+    t.p0 = mk(a.x, a.y, a.z);
+    t.e1 = mk(a.w, b.x, b.y);
+    t.e2 = mk(b.z, b.w, c.x);
+    t.ng = mk(c.y, c.z, c.w);
+    return t;
+}
+
+__device__ __forceinline__ float flipsign(float x, bool neg) { return neg ? -x : x; }
+
+// Embree-3 style Moeller-Trumbore with tnear = 0, tfar = inf.  On a hit writes
+// t and the barycentrics (u -> 2nd vertex, v -> 3rd vertex).
+__device__ __forceinline__ bool tri_test(const Tri& tr, V3 o, V3 d, float& t, float& u, float& v) {
+    V3 c = tr.p0 - o;
+    V3 r = cross(c, d);
+    float den = dot(tr.ng, d);
+    float aden = fabsf(den);
+    bool sg = (__float_as_uint(den) >> 31) != 0u;
+    float U = flipsign(dot(r, tr.e2), sg);
+    float Vv = flipsign(dot(r, tr.e1), sg);
+    bool ok = (den != 0.0f) && (U >= 0.0f) && (Vv >= 0.0f) && (U + Vv <= aden);
+    if (!ok) return false;
+    float Tn = flipsign(dot(tr.ng, c), sg);
+    if (!(0.0f < Tn)) return false;
+    float rcp = 1.0f / aden;
+    u = U * rcp;
+    v = Vv * rcp;
+    t = Tn * rcp;
+    return true;
+}
+
+// -------------------------------------------------------------- BVH node (32 B)
+// Nodes are stored in DFS pre-order.  a = (lo.x, lo.y, lo.z, hi.x),
+// b = (hi.y, hi.z, escape, tri): on a box hit an inner node continues at i+1,
+// otherwise (miss, or leaf) traversal continues at `escape` -- no stack.
+// tri >= 0 marks a leaf (index into the sorted triangle array).
+struct RayBox {
+    float ox, oy, oz, ix, iy, iz;
+};
+
+__device__ __forceinline__ float safe_inv(float d) {
+    // box tests only (conservative); the triangle test always uses the true d
+    float ad = fabsf(d);
+    float s = ad < 1e-20f ? copysignf(1e-20f, d) : d;
+    return 1.0f / s;
+}
+
+__device__ __forceinline__ bool box_test(float4 a, float4 b, const RayBox& r, float tmax) {
+    float t0x = (a.x - r.ox) * r.ix, t1x = (a.w - r.ox) * r.ix;
+    float t0y = (a.y - r.oy) * r.iy, t1y = (b.x - r.oy) * r.iy;
+    float t0z = (a.z - r.oz) * r.iz, t1z = (b.y - r.oz) * r.iz;
+    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    // widen by a few ulp: boxes are padded at build time, this covers the slab arithmetic
+    tn = tn - fabsf(tn) * 4e-7f;
+    tf = tf + fabsf(tf) * 4e-7f;
+    return fmaxf(tn, 0.0f) <= fminf(tf, tmax);
+}
+
+// Is the ray (o, d) blocked before the hit on triangle `self` at distance t_self?
+// Equivalent to "closest hit over all faces (ties -> lowest original face id) is
+// not `self`", the reference's acceptance rule primID == triangleIndex
+// (smoothed_transient/transient_and_gradient.cpp:206), but with early exit.
+__device__ __forceinline__ bool occluded(const float4* __restrict__ nodes, int n_nodes,
+                                         const float4* __restrict__ tris,
+                                         const int* __restrict__ face_id,
+                                         V3 o, V3 d, float t_self, int self, int self_fid) {
+    RayBox rb;
+    rb.ox = o.x; rb.oy = o.y; rb.oz = o.z;
+    rb.ix = safe_inv(d.x); rb.iy = safe_inv(d.y); rb.iz = safe_inv(d.z);
+    int i = 0;
+    while (i < n_nodes) {
+        int leaf = -1;
+        while (i < n_nodes) {
+            float4 a = nodes[2 * i], b = nodes[2 * i + 1];
+            bool hit = box_test(a, b, rb, t_self);
+            int esc = __float_as_int(b.z);
+            int tri = __float_as_int(b.w);
+            if (hit && tri >= 0) { leaf = tri; i = esc; break; }
+            i = hit ? i + 1 : esc;
+        }
+        if (leaf >= 0 && leaf != self) {
+            Tri tr = load_tri(tris, leaf);
+            float t, u, v;
+            if (tri_test(tr, o, d, t, u, v)) {
+                if (t < t_self || (t == t_self && face_id[leaf] < self_fid)) return true;
+            }
+        }
+    }
+    return false;
+}
+
+// Closest hit (row E).  Returns the sorted triangle index or -1.
+__device__ __forceinline__ int closest_hit(const float4* __restrict__ nodes, int n_nodes,
+                                           const float4* __restrict__ tris,
+                                           const int* __restrict__ face_id,
+                                           V3 o, V3 d, float& bt, float& bu, float& bv) {
+    RayBox rb;
+    rb.ox = o.x; rb.oy = o.y; rb.oz = o.z;
+    rb.ix = safe_inv(d.x); rb.iy = safe_inv(d.y); rb.iz = safe_inv(d.z);
+    int best = -1, best_fid = 0x7fffffff;
+    bt = __int_as_float(0x7f800000);
+    int i = 0;
+    while (i < n_nodes) {
+        float4 a = nodes[2 * i], b = nodes[2 * i + 1];
+        bool hit = box_test(a, b, rb, bt);
+        int esc = __float_as_int(b.z);
+        int tri = __float_as_int(b.w);
+        if (hit && tri >= 0) {
+            Tri tr = load_tri(tris, tri);
+            float t, u, v;
+            if (tri_test(tr, o, d, t, u, v)) {
+                int fid = face_id[tri];
+                if (best < 0 || t < bt || (t == bt && fid < best_fid)) {
+                    best = tri; best_fid = fid; bt = t; bu = u; bv = v;
+                }
+            }
+        }
+        i = (hit && tri < 0) ? i + 1 : esc;
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------- GGX (row B)
+// ggx/ggx_confocal.cpp:13-232 -- scalar functions of nw = dot(normal, w).
+// M_PI terms evaluate in double exactly as the reference's expressions do.
+#define NLOS_PI 3.14159265358979323846
+__device__ __forceinline__ float ggx_D(float a, float nw) {
+    if (nw <= 0) return 0.0f;
+    float nw2 = nw * nw;
+    float bex = (1.0f - nw2) / (a * a) / nw2;
+    float root = (1.0f + bex) * nw2;
+    float result = (float)(1.0f / (NLOS_PI * a * a * root * root));
+    if (result * nw < 1e-20f) result = 0;
+    return result;
+}
+__device__ __forceinline__ float ggx_G1(float a, float nw) {
+    if (nw <= 0) return 0.0f;
+    if ((nw >= 1.0f) || (nw <= -1.0f)) return 1.0f;
+    float root = a * a + (1.0f - a * a) * nw * nw;
+    return 2.0f / (nw + sqrtf(root));
+}
+__device__ __forceinline__ float ggx_G(float a, float nw) { float g = ggx_G1(a, nw); return g * g; }
+__device__ __forceinline__ float ggx_eval(float a, float nw) {
+    if (nw <= 0) return 0.0f;
+    float Dv = ggx_D(a, nw);
+    if (Dv == 0) return 0.0f;
+    return Dv * ggx_G(a, nw) / 4.0f;
+}
+__device__ __forceinline__ float ggx_D_adiff(float a, float nw) {
+    if (nw <= 0) return 0.0f;
+    float nw2 = nw * nw, a2 = a * a;
+    float val = a2 * nw2 - nw2 + 1;
+    return (float)(-(2.0f * a * (a2 * nw2 + nw2 - 1)) / (NLOS_PI * val * val * val));
+}
+__device__ __forceinline__ float ggx_G1_adiff(float a, float nw) {
+    if (nw <= 0) return 0.0f;
+    if ((nw >= 1.0f) || (nw <= -1.0f)) return 0.0f;
+    float nw2 = nw * nw;
+    float val = sqrtf(a * a - nw2 * (a * a - 1));
+    float root = nw + val;
+    return 2.0f * a * (nw2 - 1.0f) / (val * root * root);
+}
+__device__ __forceinline__ float ggx_eval_adiff(float a, float nw) {
+    if (nw <= 0) return 0.0f;
+    float Dv = ggx_D(a, nw);
+    if (Dv == 0) return 0.0f;
+    float Gv = ggx_G(a, nw);
+    float Dp = ggx_D_adiff(a, nw);
+    float Gp = 2.0f * ggx_G1_adiff(a, nw) * ggx_G1(a, nw);
+    return (Dp * Gv + Gp * Dv) / 4.0f;
+}
+__device__ __forceinline__ float ggx_D_ndiff(float a, float nw) {
+    if (nw <= 0) return 0.0f;
+    float nw2 = nw * nw, a2 = a * a;
+    float root = (a2 - 1.0f) * nw2 + 1.0f;
+    return (float)(-(4.0f * a2 * nw * (a2 - 1.0f)) / (NLOS_PI * root * root * root));
+}
+__device__ __forceinline__ float ggx_G1_ndiff(float a, float nw) {
+    if (nw <= 0) return 0.0f;
+    if ((nw >= 1.0f) || (nw <= -1.0f)) return 0.0f;
+    float nw2 = nw * nw, a2 = a * a;
+    float temp = sqrtf(a2 - nw2 * (a2 - 1.0f));
+    float root = nw + temp;
+    return -2.0f * (1.0f - (nw * (a2 - 1.0f)) / temp) / root / root;
+}
+// scalar s of eval_nwdiff: dnormal = s*w, dw = s*normal (0 on the early-outs)
+__device__ __forceinline__ float ggx_eval_nwsdiff(float a, float nw) {
+    if (nw <= 0) return 0.0f;
+    float Dv = ggx_D(a, nw);
+    if (Dv == 0) return 0.0f;
+    float Gv = ggx_G(a, nw);
+    float Gp = 2.0f * ggx_G1_ndiff(a, nw) * ggx_G1(a, nw);
+    float Dp = ggx_D_ndiff(a, nw);
+    return (Dp * Gv + Gp * Dv) / 4.0f;
+}
+
+}  // namespace nlos

@@ -1,0 +1,135 @@
+// nlos_kernels.h -- host-visible launchers of the gfx950 kernels (internal header).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nlos {
+
+// ------------------------------------------------------------------ BVH build
+struct BuildArgs {
+    const float* vertices;   // [V,3]
+    const int32_t* faces;    // [F,3]
+    int V, F;
+    // scratch
+    uint32_t *keys0, *keys1;
+    int *idx0, *idx1;
+    int* child;              // [2*(F-1)]
+    int* range;              // [2*(F-1)]
+    int* parent;             // [2F-1]
+    int* arrive;             // [F-1]
+    float* box;              // [6*(2F-1)]
+    int* status;             // [1] bit0: face index out of range
+    // outputs
+    float4* nodes;           // [2*(2F-1)]  pre-order, 32 B per node
+    float4* tris;            // [3*F]       48 B per triangle, Morton order
+    float4* facerec;         // [4*F]       64 B per face, Morton order
+    int* face_id;            // [F]         original face index of sorted slot j
+};
+void launch_build_bvh(const BuildArgs& a, hipStream_t stream);
+
+// ------------------------------------------------------------------ rendering
+struct SceneView {
+    const float4* nodes;
+    const float4* tris;
+    const float4* facerec;
+    const int* face_id;
+    int n_nodes, F, V;
+    const float* vertex_normal;   // [V,3] or null
+    const float* albedo;          // [V]   or null
+};
+
+struct SourceView {
+    const float* origin;     // [L,3]
+    const float* normal;     // [L,3]
+    int L;
+    long long source_offset; // global index of origin[0]
+    int total_sources;       // for 1/L
+};
+
+struct SampleParams {
+    uint64_t seed;
+    int spt;                 // samples per (source, face)
+    float lb, ub, res;       // res = bin width used for forward binning (res/refine when refined)
+    int nbins;               // bins of the forward histogram row (T * refine)
+    int clamp;               // 1: v2 clamped form factor
+    int use_ggx;
+    float ggx_alpha;
+};
+
+// forward (rows S, I, F): histogram rows + optional visibility cache
+struct ForwardArgs {
+    SceneView sc;
+    SourceView src;
+    SampleParams sp;
+    double* rows;            // [L, nbins]   overwritten
+    uint32_t* vis;           // [L, vis_words, F] accepted-sample bitmasks (or null)
+    int vis_words;
+    double* intensity;       // [F] (mode intensity: accumulated with atomics; rows unused)
+    int mode_intensity;
+};
+void launch_forward(const ForwardArgs& a, hipStream_t stream);
+
+// refined-histogram Gaussian + fold (row FD, refine > 1)
+struct SmoothArgs {
+    const double* fine;      // [L, T*refine]
+    double* transient;       // [L, T]
+    const double* kernel;    // [K]
+    int L, T, refine, sigma_bin, K;
+};
+void launch_smooth(const SmoothArgs& a, hipStream_t stream);
+
+// residual (row D) + pathlengths + optional v1 box filter (row W)
+struct ResidualArgs {
+    const double* data;      // [L,T]
+    const double* weight;    // [L,T] or null
+    const double* transient; // [L,T]
+    double* diff;            // [L,T]
+    double* pathlengths;     // [T] or null
+    int L, T;
+    int loss_test;
+    float lb, res;
+    int w_width;             // > 0: box(2w+1) (*) box(2w+1) per row, 'same' crop
+};
+void launch_residual(const ResidualArgs& a, hipStream_t stream);
+
+// gradient (rows G, GD, A, G1, vertex gradient)
+struct GradientArgs {
+    SceneView sc;
+    SourceView src;
+    SampleParams sp;         // res = caller's resolution, nbins = T
+    const double* diff;      // [L,T]
+    const uint32_t* vis;     // [L, vis_words, F]
+    int vis_words;
+    const double* tap_w;     // [K] weighting_kernal
+    const double* tap_delta; // [K] delta_length (float-evaluated, widened)
+    const double* tap_g;     // [K] (float)(delta/sigma^2*2) widened
+    int K;
+    int normal_term;         // 0/1 (already resolved)
+    int v1_style;            // 1: G1 (t1 without albedo)
+    int mode;                // 0 vertex gradient [V,3], 1 scalar albedo, 2 scalar alpha, 3 single vertex per bin
+    int vertex_num;
+    double* out;             // gradient [V,3] | scalar [1] | [T,3]
+    int lds_grad;            // 1: per-workgroup LDS accumulator (3V doubles) fits
+};
+void launch_gradient(const GradientArgs& a, hipStream_t stream);
+
+// closest-hit batch (row E)
+struct IntersectArgs {
+    SceneView sc;
+    const float* origins;    // [N,3]
+    const float* dirs;       // [N,3]
+    int n;
+    float* out3;             // [N,3] or null
+    float* out1;             // [N]   or null
+};
+void launch_intersect(const IntersectArgs& a, hipStream_t stream);
+
+// small utilities
+void launch_zero_f64(double* p, size_t n, hipStream_t stream);
+void launch_bary_to_world(const float* V, const int32_t* F, const float* bary, int n, float* out,
+                          hipStream_t stream);
+
+// LDS budget the gradient kernel may use for its accumulator (bytes)
+constexpr int kGradLdsBudget = 96 * 1024;
+
+}  // namespace nlos

@@ -1,0 +1,80 @@
+"""Mesh input helpers for the hot path's callers: Wavefront OBJ reader and a
+deterministic vertex-clustering decimator.
+
+The reference loads meshes with pyigl (`igl.readOBJ`, exp_bunny/test.py:71-77) and gets
+its ~5k-face working meshes from MATLAB (`init/cnlos_bunny_threshold_64.obj`, not in
+the repository).  These helpers produce the benchmark mesh from
+the shipped ground-truth bunny instead.
+"""
+import numpy as np
+
+
+def read_obj(path):
+    """Return (v float32 [V,3], f int32 [F,3]) from a triangle OBJ (v / f records only)."""
+    vs, fs = [], []
+    with open(path, "r") as fh:
+        for line in fh:
+            if line.startswith("v "):
+                p = line.split()
+                vs.append((float(p[1]), float(p[2]), float(p[3])))
+            elif line.startswith("f "):
+                p = line.split()[1:]
+                idx = [int(t.split("/")[0]) - 1 for t in p]
+                for k in range(1, len(idx) - 1):      # fan-triangulate polygons
+                    fs.append((idx[0], idx[k], idx[k + 1]))
+    return (np.asarray(vs, dtype=np.float32).reshape(-1, 3),
+            np.asarray(fs, dtype=np.int32).reshape(-1, 3))
+
+
+def write_obj(path, v, f):
+    with open(path, "w") as fh:
+        for p in v:
+            fh.write("v %.9g %.9g %.9g\n" % (p[0], p[1], p[2]))
+        for t in f:
+            fh.write("f %d %d %d\n" % (t[0] + 1, t[1] + 1, t[2] + 1))
+
+
+def cluster_decimate(v, f, cell):
+    """Vertex clustering on a uniform grid of edge `cell`: vertices of a cell merge into
+    their mean, faces that collapse are dropped, duplicate faces are removed.  Winding is
+    preserved.  Deterministic (pure numpy, stable sorts)."""
+    v = np.asarray(v, dtype=np.float64)
+    lo = v.min(axis=0)
+    key3 = np.floor((v - lo) / cell).astype(np.int64)
+    dims = key3.max(axis=0) + 1
+    key = (key3[:, 0] * dims[1] + key3[:, 1]) * dims[2] + key3[:, 2]
+    uniq, inv = np.unique(key, return_inverse=True)
+    cnt = np.bincount(inv, minlength=uniq.size).astype(np.float64)
+    nv = np.stack([np.bincount(inv, weights=v[:, c], minlength=uniq.size) / cnt for c in range(3)], axis=1)
+    nf = inv[np.asarray(f, dtype=np.int64)]
+    keep = (nf[:, 0] != nf[:, 1]) & (nf[:, 1] != nf[:, 2]) & (nf[:, 0] != nf[:, 2])
+    nf = nf[keep]
+    # drop duplicates regardless of rotation (keep first occurrence)
+    rot = np.argmin(nf, axis=1)
+    canon = np.stack([np.roll(r, -k) for r, k in zip(nf, rot)]) if nf.size else nf
+    _, first = np.unique(canon, axis=0, return_index=True)
+    nf = nf[np.sort(first)]
+    used = np.unique(nf)
+    remap = -np.ones(nv.shape[0], dtype=np.int64)
+    remap[used] = np.arange(used.size)
+    return nv[used].astype(np.float32), remap[nf].astype(np.int32)
+
+
+def decimate_to(v, f, target_faces, tol=0.03, iters=40):
+    """Bisect the cluster size until the face count is within `tol` of `target_faces`."""
+    v = np.asarray(v)
+    ext = float((v.max(axis=0) - v.min(axis=0)).max())
+    lo_c, hi_c = ext / 2000.0, ext / 4.0
+    best = None
+    for _ in range(iters):
+        c = np.sqrt(lo_c * hi_c)
+        nv, nf = cluster_decimate(v, f, c)
+        if best is None or abs(nf.shape[0] - target_faces) < abs(best[1].shape[0] - target_faces):
+            best = (nv, nf)
+        if abs(nf.shape[0] - target_faces) <= tol * target_faces:
+            break
+        if nf.shape[0] > target_faces:
+            lo_c = c
+        else:
+            hi_c = c
+    return best

@@ -1,0 +1,207 @@
+"""Drop-in for the reference's v2 `renderer` extension module.
+
+Mirrors transient_rendering_cython/smoothed_transient/renderer.pyx (the module every
+`exp_*` script imports through `exp_bunny/rendering.py:3,18`): same function names,
+positional signatures, typed-array checks, `assert` shape validation, in-place
+outputs and `None` return (scalar-gradient variants return a Python float).  The
+work happens in libnlos_hip.so on an MI355X; nothing here computes on the CPU.
+
+Not part of the hot path ("next"): renderStreamedNormalSmoothing,
+renderStreamedCurvatureGradient.
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from . import _lib
+from ._check import f32, f64, i32, ptr
+
+
+def _num_bins(lower_bound, upper_bound, resolution):
+    # renderer.pyx:101 -- python float math on the already-float32-rounded scalars
+    lb, ub, res = np.float32(lower_bound), np.float32(upper_bound), np.float32(resolution)
+    return math.ceil((float(ub) - float(lb)) / float(res))
+
+
+def _common(origin, normal, vertices, faces):
+    f32(origin, 2, "origin"); f32(normal, 2, "normal"); f32(vertices, 2, "vertices"); i32(faces, 2, "faces")
+    L = origin.shape[0]
+    assert origin.shape[1] == 3, "origin needs to be Lx3"
+    assert normal.shape[0] == L, "normal needs to be Lx3"
+    assert normal.shape[1] == 3, "normal needs to be Lx3"
+    assert vertices.shape[1] == 3, "vertices needs to be Vx3"
+    assert faces.shape[1] == 3, "faces needs to be Fx3"
+    return L
+
+
+def _check_tp(transient, pathlengths, L, numBins):
+    f64(transient, 2, "transient"); f64(pathlengths, 1, "pathlengths")
+    msg = "transient dimension should  be LxB   (B = math.ceil((upper_bound-lower_bound)/resolution))"
+    assert transient.shape[0] == L, msg
+    assert transient.shape[1] == numBins, msg
+    assert pathlengths.shape[0] == numBins, \
+        "pathlength dimension should be Bx1 (B = math.ceil((upper_bound-lower_bound)/resolution))"
+
+
+def _check_dw(data, weight, L, numBins):
+    f64(data, 2, "data"); f64(weight, 2, "weight")
+    msg = "data transient dimension should  be LxB   (B = math.ceil((upper_bound-lower_bound)/resolution))"
+    assert data.shape[0] == L, msg
+    assert data.shape[1] == numBins, msg
+    assert weight.shape[0] == L, "weighting should be LxB"
+    assert weight.shape[1] == numBins, "weighting should be LxB"
+
+
+def _check_grad(gradient, vertices):
+    f64(gradient, 2, "gradient")
+    assert gradient.shape[0] == vertices.shape[0], "gradient dimension should be Vx3"
+    assert gradient.shape[1] == 3, "gradient dimension should be Vx3"
+
+
+def _transient(origin, normal, vertices, vnormal, albedo, faces, num_sample, lb, ub, res,
+               transient, pathlengths, refine_scale, sigma_bin):
+    rc = _lib.lib().nlos_streamed_render_transient(
+        ptr(origin), origin.shape[0], ptr(normal), ptr(vertices), vertices.shape[0], ptr(vnormal),
+        ptr(albedo), ptr(faces), faces.shape[0], int(num_sample), lb, ub, res, ptr(transient),
+        ptr(pathlengths), int(refine_scale), int(sigma_bin))
+    _lib.check(rc, "streamed_render_transient")
+
+
+def renderStreamedTransient(origin, normal, vertices, faces, num_sample, lower_bound, upper_bound,
+                            resolution, transient, pathlengths, refine_scale, sigma_bin):
+    """renderer.pyx:175-187 -> streamed_render_transient(vertexNormal=NULL, albedo=NULL)."""
+    L = _common(origin, normal, vertices, faces)
+    _check_tp(transient, pathlengths, L, _num_bins(lower_bound, upper_bound, resolution))
+    _transient(origin, normal, vertices, None, None, faces, num_sample, lower_bound, upper_bound,
+               resolution, transient, pathlengths, refine_scale, sigma_bin)
+
+
+def renderStreamedTransientShading(origin, normal, vertices, vertexNormal, faces, num_sample,
+                                   lower_bound, upper_bound, resolution, transient, pathlengths,
+                                   refine_scale, sigma_bin):
+    """renderer.pyx:141-156 (shading normals)."""
+    L = _common(origin, normal, vertices, faces)
+    f32(vertexNormal, 2, "vertexNormal")
+    assert vertexNormal.shape[1] == 3, "vertex normal needs to be Vx3"
+    assert vertices.shape[0] == vertexNormal.shape[0], "vertex normal needs to be Vx3"
+    _check_tp(transient, pathlengths, L, _num_bins(lower_bound, upper_bound, resolution))
+    _transient(origin, normal, vertices, vertexNormal, None, faces, num_sample, lower_bound,
+               upper_bound, resolution, transient, pathlengths, refine_scale, sigma_bin)
+
+
+def renderStreamedTransientwAlbedo(origin, normal, vertices, albedo, faces, num_sample, lower_bound,
+                                   upper_bound, resolution, transient, pathlengths, refine_scale,
+                                   sigma_bin):
+    """renderer.pyx:158-172 (per-vertex albedo)."""
+    L = _common(origin, normal, vertices, faces)
+    f32(albedo, 1, "albedo")
+    assert vertices.shape[0] == albedo.shape[0], "albedo nees to be Vx1"
+    _check_tp(transient, pathlengths, L, _num_bins(lower_bound, upper_bound, resolution))
+    _transient(origin, normal, vertices, None, albedo, faces, num_sample, lower_bound, upper_bound,
+               resolution, transient, pathlengths, refine_scale, sigma_bin)
+
+
+def renderStreamedTriangleIntensity(origin, normal, vertices, faces, num_sample, lower_bound,
+                                    upper_bound, intensity):
+    """renderer.pyx:189-200 -> streamed_render_intensity."""
+    _common(origin, normal, vertices, faces)
+    f64(intensity, 1, "intensity")
+    assert intensity.shape[0] == faces.shape[0], "intensity should be (F,)"
+    rc = _lib.lib().nlos_streamed_render_intensity(
+        ptr(origin), origin.shape[0], ptr(normal), ptr(vertices), vertices.shape[0], None, ptr(faces),
+        faces.shape[0], int(num_sample), lower_bound, upper_bound, ptr(intensity))
+    _lib.check(rc, "streamed_render_intensity")
+
+
+def _gradient(fn_name, origin, normal, vertices, extra, faces, num_sample, lb, ub, res, transient,
+              pathlengths, gradient, data, weight, refine_scale, sigma_bin, testing_flag, loss_flag):
+    fn = getattr(_lib.lib(), fn_name)
+    rc = fn(ptr(data), ptr(weight), ptr(origin), origin.shape[0], ptr(normal), ptr(vertices),
+            vertices.shape[0], ptr(extra), ptr(faces), faces.shape[0], int(num_sample), lb, ub, res,
+            ptr(transient), ptr(pathlengths), ptr(gradient), int(refine_scale), int(sigma_bin),
+            int(testing_flag), int(loss_flag))
+    _lib.check(rc, fn_name)
+
+
+def renderStreamedGradient(origin, normal, vertices, faces, num_sample, lower_bound, upper_bound,
+                           resolution, transient, pathlengths, gradient, data, weight, refine_scale,
+                           sigma_bin, testing_flag, loss_flag):
+    """renderer.pyx:94-111 -> streamed_render_gradient(vertexNormal=NULL)."""
+    L = _common(origin, normal, vertices, faces)
+    numBins = _num_bins(lower_bound, upper_bound, resolution)
+    _check_tp(transient, pathlengths, L, numBins)
+    _check_grad(gradient, vertices)
+    _check_dw(data, weight, L, numBins)
+    _gradient("nlos_streamed_render_gradient", origin, normal, vertices, None, faces, num_sample,
+              lower_bound, upper_bound, resolution, transient, pathlengths, gradient, data, weight,
+              refine_scale, sigma_bin, testing_flag, loss_flag)
+
+
+def renderStreamedShadingGradient(origin, normal, vertices, faces, vertexNormal, num_sample,
+                                  lower_bound, upper_bound, resolution, transient, pathlengths,
+                                  gradient, data, weight, refine_scale, sigma_bin, testing_flag,
+                                  loss_flag):
+    """renderer.pyx:114-138 -> streamed_render_gradient(vertexNormal)."""
+    L = _common(origin, normal, vertices, faces)
+    f32(vertexNormal, 2, "vertexNormal")
+    assert vertexNormal.shape[1] == 3, "vertex normal needs to be Vx3"
+    assert vertices.shape[0] == vertexNormal.shape[0], "vertex normal needs to be Vx3"
+    numBins = _num_bins(lower_bound, upper_bound, resolution)
+    _check_tp(transient, pathlengths, L, numBins)
+    _check_grad(gradient, vertices)
+    _check_dw(data, weight, L, numBins)
+    _gradient("nlos_streamed_render_gradient", origin, normal, vertices, vertexNormal, faces,
+              num_sample, lower_bound, upper_bound, resolution, transient, pathlengths, gradient,
+              data, weight, refine_scale, sigma_bin, testing_flag, loss_flag)
+
+
+def renderStreamedGradientWithAlbedo(origin, normal, vertices, faces, albedo, num_sample, lower_bound,
+                                     upper_bound, resolution, transient, pathlengths, gradient, data,
+                                     weight, refine_scale, sigma_bin, testing_flag, loss_flag):
+    """renderer.pyx:55-75 -> streamed_render_gradient_w_albedo."""
+    L = _common(origin, normal, vertices, faces)
+    f32(albedo, 1, "albedo")
+    assert albedo.shape[0] == vertices.shape[0], "albedo needs to be Vx1"
+    numBins = _num_bins(lower_bound, upper_bound, resolution)
+    _check_tp(transient, pathlengths, L, numBins)
+    _check_grad(gradient, vertices)
+    _check_dw(data, weight, L, numBins)
+    _gradient("nlos_streamed_render_gradient_w_albedo", origin, normal, vertices, albedo, faces,
+              num_sample, lower_bound, upper_bound, resolution, transient, pathlengths, gradient,
+              data, weight, refine_scale, sigma_bin, testing_flag, loss_flag)
+
+
+def renderStreamedGradientAlbedo(origin, normal, vertices, faces, albedo, num_sample, lower_bound,
+                                 upper_bound, resolution, transient, pathlengths, data, weight,
+                                 refine_scale, sigma_bin, testing_flag, loss_flag):
+    """renderer.pyx:33-52 -> streamed_render_gradient_albedo; returns d loss / d albedo."""
+    L = _common(origin, normal, vertices, faces)
+    f32(albedo, 1, "albedo")
+    assert albedo.shape[0] == vertices.shape[0], "albedo needs to be Vx1"
+    numBins = _num_bins(lower_bound, upper_bound, resolution)
+    _check_tp(transient, pathlengths, L, numBins)
+    _check_dw(data, weight, L, numBins)
+    out = ctypes.c_double(0.0)
+    rc = _lib.lib().nlos_streamed_render_gradient_albedo(
+        ptr(data), ptr(weight), ptr(origin), L, ptr(normal), ptr(vertices), vertices.shape[0],
+        ptr(albedo), ptr(faces), faces.shape[0], int(num_sample), lower_bound, upper_bound, resolution,
+        ptr(transient), ptr(pathlengths), int(refine_scale), int(sigma_bin), int(testing_flag),
+        int(loss_flag), ctypes.cast(ctypes.byref(out), ctypes.c_void_p))
+    _lib.check(rc, "streamed_render_gradient_albedo")
+    return out.value
+
+
+def renderStreamedVertexGradient(origin, normal, vertices, faces, num_sample, lower_bound, upper_bound,
+                                 resolution, gradient, vertex_num, refine_scale, sigma_bin):
+    """renderer.pyx:78-88 -> streamed_render_vertex_gradient (measurement is hard-wired to 1)."""
+    _common(origin, normal, vertices, faces)
+    numBins = _num_bins(lower_bound, upper_bound, resolution)
+    f64(gradient, 2, "gradient")
+    assert gradient.shape[0] == numBins, "gradient dimension should be Vx3"
+    assert gradient.shape[1] == 3, "gradient dimension should be Vx3"
+    rc = _lib.lib().nlos_streamed_render_vertex_gradient(
+        int(vertex_num), ptr(origin), 1, ptr(normal), ptr(vertices), vertices.shape[0], ptr(faces),
+        faces.shape[0], int(num_sample), lower_bound, upper_bound, resolution, ptr(gradient),
+        int(refine_scale), int(sigma_bin))
+    _lib.check(rc, "streamed_render_vertex_gradient")
