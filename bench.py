@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: confocal transient forward + per-vertex gradient on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one `renderStreamedGradient`-equivalent call on device-resident inputs
+(BVH build + pass 1 + residual + pass 2), plus -- for N > 1 -- the single
+RCCL all-reduce of the 3V-double vertex gradient.  Workload (N = 1): BASELINE.json's metric
+configuration, 64x64 confocal sources x 512 bins on the ~5k-face bunny, num_sample = 20000
+(spt = 5), refine = 10, sigma_bin = 1.  For N > 1 every rank renders its own 64x64 block of a
+64 x 64N grid (weak scaling; `--scaling strong` splits one 64x64 grid instead).
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the launch
+stream (nlos_ctx_last_timing); `cpu_baseline` times the CPU oracle (a port of the reference
+algorithm, kind "port") on a bounded sample of the same workload, on rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "surface samples/sec fwd+grad; 64x64 sensors x 512 bins, bunny mesh"
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def grid_sources(nx, ny, half):
+    gx = np.linspace(-half, half, nx)
+    gy = np.linspace(-half, half, ny)
+    origin = np.array([[x, y, 0] for y in gy for x in gx], np.float32)
+    normal = np.tile(np.array([0, 0, 1], np.float32), (origin.shape[0], 1))
+    return origin, normal
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/pmc_summary.json; collected in separate --pmc passes, FETCH_SIZE doubled as the
+    gfx950 correction of MI355X_MICROARCH.md section HBM prescribes).  None if absent."""
+    p = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        with open(p) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(v, f, origin, normal, lb, ub, res, num_sample, data_rows, budget_s=15.0):
+    """Oracle (CPU port of the reference algorithm, own BVH, per-thread buffers, literal 41-tap
+    loop) timed on a bounded sample of the same workload: the first `n` sources."""
+    import oracle
+    oracle.build()
+    cores = os.cpu_count() or 1
+    F = f.shape[0]
+    spt = 1 + (num_sample - 1) // F
+
+    def run(n):
+        o, nn = np.ascontiguousarray(origin[:n]), np.ascontiguousarray(normal[:n])
+        d = np.ascontiguousarray(data_rows[:n])
+        w = np.ones_like(d)
+        t0 = time.perf_counter()
+        oracle.render_gradient(o, nn, v, f, num_sample, lb, ub, res, d, w, refine=10, sigma_bin=1,
+                               testing_flag=1, loss_flag=0, accel=1, threads=cores, seed=0)
+        return time.perf_counter() - t0
+
+    n0 = min(8, origin.shape[0])
+    t_probe = run(n0)
+    n = int(max(n0, min(origin.shape[0], n0 * budget_s / max(t_probe, 1e-3))))
+    t = run(n)
+    return {"value": n * F * spt / t, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "first %d of the %d sources of the same workload (%.1f s of CPU work), oracle with "
+                      "its own BVH, OpenMP over (source, face) with per-thread buffers" % (n, origin.shape[0], t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=64, help="sources per side per GPU (64 -> 64x64)")
+    ap.add_argument("--bins", type=int, default=512)
+    ap.add_argument("--num-sample", type=int, default=20000)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--forward-only", action="store_true", help="BASELINE config 2 (parity-run size, not the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from nlos_surface_optimization_amd import device as nd
+    from nlos_surface_optimization_amd import dist as ndist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" IS RCCL on ROCm
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    d = np.load(os.path.join(ROOT, "tests", "golden", "bunny_5k.npz"))
+    v_np = np.ascontiguousarray(d["v"], np.float32)
+    f_np = np.ascontiguousarray(d["f"], np.int32)
+    F, V = f_np.shape[0], v_np.shape[0]
+    T = args.bins
+    lb, ub, res = 0.625, 1.625, 1.0 / T          # exact in fp32 for T = 512 / 1024
+    spt = 1 + (args.num_sample - 1) // F
+
+    g = args.grid
+    if args.scaling == "weak":
+        origin_np, normal_np = grid_sources(g, g * world, 0.25)    # 64 x 64N grid, one 64x64 block per rank
+    else:
+        origin_np, normal_np = grid_sources(g, g, 0.25)
+    L_total = origin_np.shape[0]
+    lo, hi = ndist.shard_bounds(L_total, rank, world)
+    L = hi - lo
+
+    r = nd.TransientRenderer(dev, seed=0)
+    r.enable_timing(True)
+    origin = torch.from_numpy(origin_np[lo:hi]).to(dev)
+    normal = torch.from_numpy(normal_np[lo:hi]).to(dev)
+    faces = torch.from_numpy(f_np).to(dev)
+    verts = torch.from_numpy(v_np).to(dev)
+    # synthetic measurement: transient of a slightly displaced copy of the mesh, weight == 1
+    rs = np.random.RandomState(0)
+    v_gt = torch.from_numpy((v_np + 0.002 * rs.standard_normal(v_np.shape)).astype(np.float32)).to(dev)
+    data, _ = r.render_transient(origin, normal, v_gt, faces, args.num_sample, lb, ub, res,
+                                 source_offset=lo, total_sources=L_total, seed=1)
+    weight = torch.ones_like(data)
+    grad = torch.zeros((V, 3), dtype=torch.float64, device=dev)
+
+    def step():
+        grad.zero_()
+        if args.forward_only:
+            r.render_transient(origin, normal, verts, faces, args.num_sample, lb, ub, res,
+                               source_offset=lo, total_sources=L_total)
+        else:
+            r.render_gradient(origin, normal, verts, faces, args.num_sample, lb, ub, res, data=data,
+                              weight=weight, refine_scale=10, sigma_bin=1, testing_flag=1, loss_flag=0,
+                              gradient=grad, source_offset=lo, total_sources=L_total)
+            if world > 1:
+                dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    r.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    # per-kernel durations: HIP events recorded on the launch stream inside the timed region
+    kt = np.array(r.timing_mean_ms()[0])
+
+    if rank == 0:
+        samples_per_step = L_total * F * spt          # all ranks
+        ms = 1e3 * elapsed / args.steps
+        out = {
+            "metric": METRIC,
+            "value": samples_per_step * args.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": args.scaling,
+            "vs_baseline": None,
+            "dtype": "f32 per-sample math, f64 accumulation",
+            "data": "synthetic",
+            "config": {
+                "workload": ("forward-only " if args.forward_only else "forward+gradient ") +
+                            "%dx%d confocal sources per GPU x %d bins, bunny_5k (F=%d, V=%d), num_sample=%d "
+                            "(spt=%d), refine=10, sigma_bin=1, BVH rebuilt every step" % (g, g, T, F, V, args.num_sample, spt),
+                "sources_total": L_total, "faces": F, "bins": T, "spt": spt,
+                "parallelism": "source-block sharding x%d + one all-reduce of the 3V gradient" % world,
+            },
+        }
+        # roofline of the dominant kernel, measured live (HIP events, rank 0, this rank's launches)
+        names = ["bvh_build", "k_forward", "k_residual", "k_gradient"]
+        dom = int(np.argmax(kt))
+        per_sample = {"k_forward": 16.0 + 36.0 / spt, "k_gradient": 184.0 + 36.0 / spt}.get(names[dom], 0.0)
+        local_samples = L * F * spt
+        if kt[dom] > 0 and per_sample > 0:
+            achieved = per_sample * local_samples / (kt[dom] * 1e-3) / 1e9
+            pmc = load_pmc_traffic()
+            traffic = None
+            if pmc and pmc.get("kernel") == names[dom] and pmc.get("L") == L and pmc.get("F") == F:
+                traffic = pmc.get("hbm_bytes_per_launch")
+            out["roofline"] = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "algorithmic_bytes_per_sample": per_sample,
+                               "kernel_ms": {n: float(x) for n, x in zip(names, kt)},
+                               "step_algorithmic_GBps": (200.0 + 72.0 / spt) * local_samples / (ms * 1e-3) / 1e9}
+        if world == 1 and not args.no_cpu_baseline and not args.forward_only:
+            out["cpu_baseline"] = cpu_baseline(v_np, f_np, origin_np, normal_np, lb, ub, res, args.num_sample,
+                                               data.cpu().numpy())
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -221,6 +221,10 @@ int nlos_num_bins(float lower_bound, float upper_bound, float resolution);
  * [3]=gradient; valid after the stream is synchronised.  enable first. */
 void nlos_ctx_enable_timing(nlos_ctx *ctx, int enable);
 int  nlos_ctx_last_timing(nlos_ctx *ctx, float *ms4);
+/* the event sets live in a ring (256 renders), so a timed loop needs no host sync:
+ * reset before the loop, read the per-stage means after the final synchronise */
+void nlos_ctx_timing_reset(nlos_ctx *ctx);
+int  nlos_ctx_timing_mean(nlos_ctx *ctx, float *ms4, int *count);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,8 @@ SYMBOLS = {
     "nlos_num_bins": (_I, [_F, _F, _F]),
     "nlos_ctx_enable_timing": (None, [_P, _I]),
     "nlos_ctx_last_timing": (_I, [_P, _P]),
+    "nlos_ctx_timing_reset": (None, [_P]),
+    "nlos_ctx_timing_mean": (_I, [_P, _P, _P]),
 }
 
 
@@ -121,10 +123,35 @@ def build(force=False):
     return LIB_PATH
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64.so
+    (SONAME libamdhip64.so.7, loaded by file name through RPATH $ORIGIN), while libnlos_hip.so
+    asks for libamdhip64.so.7 and would otherwise bind /opt/rocm's copy: two runtimes in one
+    process, and whichever initialises second sees no GPU.  Pre-loading torch's copy (when
+    torch is installed) makes the dynamic linker resolve both requests to the same object,
+    whatever the import order.  Without torch the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return None
+    try:
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        return None
+    return cand
+
+
 def lib():
     """Load the shared library (never builds implicitly on a GPU box: ship the .so)."""
     global _lib
     if _lib is None:
+        _preload_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise NlosError(
                 "libnlos_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

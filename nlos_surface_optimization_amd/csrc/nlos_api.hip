@@ -87,8 +87,13 @@ struct nlos_ctx {
     struct VisKey { int L = -1, F = -1, V = -1, spt = -1; long long off = -1; uint64_t seed = 0; float lb = 0, ub = 0;
                     int feat = -1; } vis_key;
     // timing
+    // ring of event sets: no host sync inside a timed loop, read back after the final sync
+    static constexpr int kRing = 256;
     bool timing = false;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ring;    // kRing * 5 events, created on enable
+    int ring_head = 0;               // next slot to record into
+    int ring_count = 0;              // slots recorded since the last reset (saturates at kRing)
+    hipEvent_t* ev = nullptr;        // slot being recorded by the current render
     bool ev_valid = false;
 };
 
@@ -196,7 +201,14 @@ nlos::SceneView scene_view(const nlos_ctx* c, int nF, int nV, const float* vn, c
 }
 
 void mark(nlos_ctx* c, int i, hipStream_t st) {
-    if (c->timing) { hipError_t e = hipEventRecord(c->ev[i], st); (void)e; }
+    if (!c->timing || c->ring.empty()) return;
+    if (i == 0) c->ev = &c->ring[(size_t)c->ring_head * 5];
+    hipError_t e = hipEventRecord(c->ev[i], st);
+    (void)e;
+    if (i == 4) {
+        c->ring_head = (c->ring_head + 1) % nlos_ctx::kRing;
+        if (c->ring_count < nlos_ctx::kRing) ++c->ring_count;
+    }
 }
 
 }  // namespace
@@ -240,7 +252,7 @@ void nlos_ctx_destroy(nlos_ctx* c) {
                      &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp};
     for (DevBuf* b : all) b->release();
     for (DevBuf& b : c->io) b.release();
-    for (hipEvent_t& e : c->ev) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
+    for (hipEvent_t& e : c->ring) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
     delete c;
 }
 
@@ -259,20 +271,50 @@ void nlos_ctx_enable_timing(nlos_ctx* c, int enable) {
     if (!c) return;
     DeviceGuard g(c->device);
     c->timing = enable != 0;
-    if (c->timing)
-        for (hipEvent_t& e : c->ev)
-            if (!e) { hipError_t r = hipEventCreate(&e); (void)r; }
+    if (c->timing && c->ring.empty()) {
+        c->ring.assign((size_t)nlos_ctx::kRing * 5, nullptr);
+        for (hipEvent_t& e : c->ring) { hipError_t r = hipEventCreate(&e); (void)r; }
+    }
+    c->ring_head = 0; c->ring_count = 0; c->ev_valid = false;
+}
+
+void nlos_ctx_timing_reset(nlos_ctx* c) {
+    if (!c) return;
+    c->ring_head = 0; c->ring_count = 0; c->ev_valid = false;
+}
+
+static int slot_times(nlos_ctx* c, int slot, float* ms4) {
+    hipEvent_t* ev = &c->ring[(size_t)slot * 5];
+    for (int i = 0; i < 4; ++i) {
+        ms4[i] = 0.0f;
+        hipError_t e = hipEventElapsedTime(&ms4[i], ev[i], ev[i + 1]);
+        if (e != hipSuccess) return fail(NLOS_ERR_HIP, std::string("hipEventElapsedTime: ") + hipGetErrorString(e));
+    }
+    return NLOS_OK;
 }
 
 int nlos_ctx_last_timing(nlos_ctx* c, float* ms4) {
     if (!c || !ms4) return fail(NLOS_ERR_ARG, "nlos_ctx_last_timing: NULL argument");
-    if (!c->timing || !c->ev_valid) return fail(NLOS_ERR_ARG, "timing not enabled or no render recorded");
+    if (!c->timing || c->ring_count == 0) return fail(NLOS_ERR_ARG, "timing not enabled or no render recorded");
     DeviceGuard g(c->device);
-    for (int i = 0; i < 4; ++i) {
-        ms4[i] = 0.0f;
-        hipError_t e = hipEventElapsedTime(&ms4[i], c->ev[i], c->ev[i + 1]);
-        if (e != hipSuccess) return fail(NLOS_ERR_HIP, std::string("hipEventElapsedTime: ") + hipGetErrorString(e));
+    int slot = (c->ring_head + nlos_ctx::kRing - 1) % nlos_ctx::kRing;
+    return slot_times(c, slot, ms4);
+}
+
+int nlos_ctx_timing_mean(nlos_ctx* c, float* ms4, int* count) {
+    if (!c || !ms4) return fail(NLOS_ERR_ARG, "nlos_ctx_timing_mean: NULL argument");
+    if (!c->timing || c->ring_count == 0) return fail(NLOS_ERR_ARG, "timing not enabled or no render recorded");
+    DeviceGuard g(c->device);
+    double acc[4] = {0, 0, 0, 0};
+    for (int k = 0; k < c->ring_count; ++k) {
+        int slot = (c->ring_head + nlos_ctx::kRing - 1 - k) % nlos_ctx::kRing;
+        float t[4];
+        int rc = slot_times(c, slot, t);
+        if (rc) return rc;
+        for (int i = 0; i < 4; ++i) acc[i] += t[i];
     }
+    for (int i = 0; i < 4; ++i) ms4[i] = (float)(acc[i] / c->ring_count);
+    if (count) *count = c->ring_count;
     return NLOS_OK;
 }
 

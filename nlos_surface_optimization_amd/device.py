@@ -78,6 +78,18 @@ class TransientRenderer:
         _lib.check(self._lib.nlos_ctx_last_timing(self._h, ctypes.cast(buf, ctypes.c_void_p)), "nlos_ctx_last_timing")
         return tuple(float(x) for x in buf)
 
+    def timing_reset(self):
+        self._lib.nlos_ctx_timing_reset(self._h)
+
+    def timing_mean_ms(self):
+        """Per-stage mean over the renders since timing_reset() (ring of 256); synchronises."""
+        torch.cuda.current_stream(self.device).synchronize()
+        buf = (ctypes.c_float * 4)()
+        cnt = ctypes.c_int(0)
+        _lib.check(self._lib.nlos_ctx_timing_mean(self._h, ctypes.cast(buf, ctypes.c_void_p),
+                                                  ctypes.cast(ctypes.byref(cnt), ctypes.c_void_p)), "nlos_ctx_timing_mean")
+        return tuple(float(x) for x in buf), cnt.value
+
     def _args(self, mode, origin, normal, vertices, faces, num_sample, lower_bound, upper_bound,
               resolution, refine_scale=1, sigma_bin=1, vertex_normal=None, albedo=None,
               source_offset=0, total_sources=0, alpha=None, seed=None):
