@@ -202,6 +202,7 @@ typedef struct nlos_render_args {
                                    previous render on this ctx (same mesh, sources, samples, seed) */
 } nlos_render_args;
 
+int  nlos_sizeof_render_args(void);                 /* for FFI layout checks */
 void nlos_render_args_init(nlos_render_args *a);   /* zero + defaults (clamp=1, normal_term=-1, refine=1, sigma_bin=1) */
 
 /* Enqueue one render on `stream` (hipStream_t as void*; NULL = default stream).

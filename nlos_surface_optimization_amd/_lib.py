@@ -100,6 +100,7 @@ SYMBOLS = {
     "nlos_ctx_create": (_I, [_I, ctypes.POINTER(ctypes.c_void_p)]),
     "nlos_ctx_destroy": (None, [_P]),
     "nlos_ctx_scratch_bytes": (_I64, [_P]),
+    "nlos_sizeof_render_args": (_I, []),
     "nlos_render_args_init": (None, [ctypes.POINTER(RenderArgs)]),
     "nlos_render": (_I, [_P, ctypes.POINTER(RenderArgs), _P]),
     "nlos_intersect": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _P, _P, _P]),

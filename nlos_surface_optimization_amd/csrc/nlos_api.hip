@@ -219,6 +219,8 @@ const char* nlos_last_error(void) { return g_err.c_str(); }
 
 int nlos_version(void) { return 100; }
 
+int nlos_sizeof_render_args(void) { return (int)sizeof(nlos_render_args); }
+
 int nlos_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -62,6 +62,7 @@ def make_pyref():
     """Run the reference's numpy prototype (imported, not copied) on fixed inputs."""
     sys.path.insert(0, os.path.join(REF, "transient_rendering_python"))
     import rendering as pyref  # noqa: E402  (the reference module)
+    import mesh_intersection as pyint  # noqa: E402  (the reference module)
 
     out = {}
     rs = np.random.RandomState(0)
@@ -91,12 +92,21 @@ def make_pyref():
         opt.distance_resolution = 0.02
         opt.epsilon = 1e-9
         opt.normal = "fn"
-        res = []
+        res, prims, tnear = [], [], []
         for lighting, sensor in pairs:
             lighting = np.array(lighting, np.float64)
             sensor = np.array(sensor, np.float64)
             t = pyref.angular_sampling(mesh, d, lighting, sensor, np.array([0, 0, 1.0]), np.array([0, 0, 1.0]), opt)
             res.append(np.array(t))
+            # per-ray nearest hit as the prototype selects it (rendering.py:37-52)
+            hit, tt, _, _ = pyint.intersect_ray_mesh_batch_directions(lighting, d, mesh, opt.epsilon)
+            tabs = np.where(hit, np.abs(tt), np.inf)
+            pr = np.where(hit.any(axis=0), np.argmin(tabs, axis=0), -1)
+            prims.append(pr)
+            tnear.append(np.where(pr >= 0, tabs.min(axis=0), np.nan))
+        out[name + "_prim"] = np.stack(prims)
+        out[name + "_tnear"] = np.stack(tnear)
+        out[name + "_fn"] = fn
         out[name + "_v"] = mv
         out[name + "_f"] = mf
         out[name + "_dir"] = d
@@ -126,12 +136,12 @@ def make_oracle_cfg1():
 def make_oracle_bunny(v, f):
     origin, normal = grid_sources(4, 0.25)
     lb, ub, res = 0.625, 1.625, 2.0 ** -9
-    tr, path = orc.render_transient(origin, normal, v, f, 20000, lb, ub, res, seed=0, accel=1)
+    tr, path = orc.render_transient(origin, normal, v, f, 20000, lb, ub, res, seed=0, accel=1, threads=1)
     rs = np.random.RandomState(1)
     data = tr * (1.0 + 0.3 * rs.standard_normal(tr.shape))
     weight = 0.5 + rs.random_sample(tr.shape)
     _, grad, _ = orc.render_gradient(origin, normal, v, f, 20000, lb, ub, res, data, weight, refine=10,
-                                     sigma_bin=1, testing_flag=1, loss_flag=0, seed=0, accel=1)
+                                     sigma_bin=1, testing_flag=1, loss_flag=0, seed=0, accel=1, threads=1)
     np.savez_compressed(os.path.join(HERE, "oracle_bunny16.npz"), origin=origin, normal=normal, lb=lb, ub=ub,
                         res=res, num_sample=20000, transient=tr, data=data, weight=weight, gradient=grad)
     print("bunny16 rows", tr.sum(axis=1)[:4], "grad", np.abs(grad).max())

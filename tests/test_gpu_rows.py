@@ -1,0 +1,257 @@
+"""GPU parity for the remaining rows of SURVEY.md section 8a (X, A, B, E, G1/W, single-vertex
+gradient), the device-tensor / autograd path, source sharding, and size-independent properties
+at BASELINE config-2 size.  Same tolerances as test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, grid_sources, rel_l2, vertex_normals
+
+pytestmark = pytest.mark.gpu
+
+LB, UB, RES, T = 0.625, 1.625, 2.0 ** -9, 512
+
+
+def _setup(bunny, n=2, ns=9000, seed=3, orc=None):
+    v, f = bunny
+    origin, normal = grid_sources(n, 0.2)
+    return v, f, origin, normal, ns
+
+
+def test_intensity_row_x(bunny, orc):
+    from nlos_surface_optimization_amd import renderer
+    v, f, origin, normal, ns = _setup(bunny)
+    inten = np.zeros(f.shape[0])
+    renderer.renderStreamedTriangleIntensity(origin, normal, v, f, ns, 0.0, 2.0, inten)
+    ref = orc.render_intensity(origin, normal, v, f, ns, 0.0, 2.0, accel=1)
+    assert rel_l2(inten, ref) <= 1e-12
+    assert (inten > 0).sum() > 100 and (inten == 0).sum() > 100       # lit and unlit faces both present
+    # accumulates into the caller's buffer
+    renderer.renderStreamedTriangleIntensity(origin, normal, v, f, ns, 0.0, 2.0, inten)
+    assert rel_l2(inten, 2 * ref) <= 1e-12
+
+
+def test_intersector_row_e(bunny, orc):
+    from nlos_surface_optimization_amd import embree_intersector as ei
+    v, f = bunny
+    rs = np.random.RandomState(11)
+    n = 50000
+    o = np.zeros((n, 3), np.float32)
+    o[:, :2] = rs.uniform(-0.3, 0.3, (n, 2))
+    tgt = v[rs.randint(0, v.shape[0], n)] + rs.normal(0, 0.01, (n, 3)).astype(np.float32)
+    d = np.ascontiguousarray((tgt - o).astype(np.float32))           # un-normalised directions
+    out = np.full((n, 3), 123.0, np.float32)
+    ei.embree3_tbb_intersection(o, d, v, f, out)
+    ref = orc.intersect(o, d, v, f, accel=1)
+    hit = ref[:, 0] >= 0
+    assert np.array_equal(out[:, 0], ref[:, 0])                       # bit-exact primIDs (and -1 on miss)
+    assert np.array_equal(out[hit], ref[hit])                         # bit-exact barycentrics
+    assert np.all(out[~hit, 1:] == 123.0)                             # u, v untouched on a miss
+    assert 0.3 < hit.mean() < 1.0
+    short = np.zeros(n, np.float32)
+    ei.embree3_tbb_short_intersection(o, d, v, f, short)
+    assert np.array_equal(short, ref[:, 0])
+    pts = np.full((n, 3), -5.0, np.float32)
+    ei.barycoord_to_world(v, f, out, pts)
+    ref_pts = orc.barycentric_to_world(v, f, ref)
+    assert np.allclose(pts[hit], ref_pts[hit], rtol=0, atol=1e-6)
+    assert np.all(pts[~hit] == -5.0)
+    m = ei.PyMesh(v, f)
+    out2 = np.zeros((n, 3), np.float32)
+    m.embree3_tbb_intersection(o, d, out2)
+    assert np.array_equal(out2[:, 0], ref[:, 0])
+
+
+def test_space_carving_projection(bunny):
+    import types
+    from nlos_surface_optimization_amd import rendering
+    v, f = bunny
+    mesh = types.SimpleNamespace(v=v, f=f)
+    pts = np.array([[0.0, 0.05, 0.30], [0.0, 0.05, 0.60], [0.4, 0.4, 0.5]], np.float32)
+    before = pts.copy()
+    rendering.space_carving_projection(pts, mesh)
+    assert pts[0, 2] > before[0, 2] and pts[0, 2] >= v[:, 2].min()   # pushed back onto the carved surface
+    assert pts[1, 2] == before[1, 2]                                  # already behind it
+    assert np.array_equal(pts[2], before[2])                          # ray misses the mesh
+
+
+def test_scalar_gradients_rows_a_and_alpha(bunny, orc):
+    from nlos_surface_optimization_amd import ggx, renderer
+    v, f, origin, normal, ns = _setup(bunny)
+    rs = np.random.RandomState(5)
+    base, _ = orc.render_transient(origin, normal, v, f, ns, LB, UB, RES, accel=1)
+    data = base * (1 + 0.3 * rs.standard_normal(base.shape))
+    w = 0.5 + rs.random_sample(base.shape)
+    alb = np.full(v.shape[0], 0.8, np.float32)
+    tr, path = np.zeros((4, T)), np.zeros(T)
+    g = renderer.renderStreamedGradientAlbedo(origin, normal, v, f, alb, ns, LB, UB, RES, tr, path, data, w, 10, 1, 1, 0)
+    t_o, g_o = orc.render_gradient_scalar(origin, normal, v, f, ns, LB, UB, RES, data, w, albedo=alb, accel=1)
+    assert rel_l2(tr, t_o) <= 1e-5 and abs(g - g_o) <= 1e-6 * abs(g_o)
+    g = ggx.renderStreamedGradientAlpha(origin, normal, v, f, 0.3, ns, LB, UB, RES, tr, path, data, w, 10, 1)
+    t_o, g_o = orc.render_gradient_scalar(origin, normal, v, f, ns, LB, UB, RES, data, w, wrt_alpha=True,
+                                          ggx_alpha=0.3, accel=1)
+    assert rel_l2(tr, t_o) <= 1e-5 and abs(g - g_o) <= 1e-5 * abs(g_o)
+
+
+@pytest.mark.parametrize("shading", [False, True])
+def test_ggx_branch_row_b(bunny, orc, shading):
+    from nlos_surface_optimization_amd import ggx
+    v, f, origin, normal, ns = _setup(bunny)
+    vn = vertex_normals(v, f) if shading else None
+    rs = np.random.RandomState(6)
+    tr, path, grad = np.zeros((4, T)), np.zeros(T), np.zeros((v.shape[0], 3))
+    if shading:
+        ggx.renderStreamedTransientShading(origin, normal, v, vn, f, 0.3, ns, LB, UB, RES, tr, path, 1, 1)
+    else:
+        ggx.renderStreamedTransient(origin, normal, v, f, 0.3, ns, LB, UB, RES, tr, path, 1, 1)
+    t_o, _ = orc.render_transient(origin, normal, v, f, ns, LB, UB, RES, vnormal=vn, ggx_alpha=0.3, accel=1)
+    assert rel_l2(tr, t_o) <= 1e-5 and tr.sum() > 0
+    data = t_o * (1 + 0.3 * rs.standard_normal(t_o.shape))
+    w = np.ones_like(data)
+    if shading:
+        ggx.renderStreamedShadingGradient(origin, normal, v, f, vn, 0.3, ns, LB, UB, RES, tr, path, grad, data, w, 10, 1, 0)
+    else:
+        ggx.renderStreamedGradient(origin, normal, v, f, 0.3, ns, LB, UB, RES, tr, path, grad, data, w, 10, 1, 0)
+    _, g_o, _ = orc.render_gradient(origin, normal, v, f, ns, LB, UB, RES, data, w, vnormal=vn, ggx_alpha=0.3,
+                                    testing_flag=0, accel=1)
+    assert rel_l2(grad, g_o) <= 1e-4
+    inten = np.zeros(f.shape[0])
+    ggx.renderStreamedTriangleIntensity(origin, normal, v, f, 0.3, ns, 0.0, 2.0, inten)
+    assert rel_l2(inten, orc.render_intensity(origin, normal, v, f, ns, 0.0, 2.0, ggx_alpha=0.3, accel=1)) <= 1e-12
+
+
+def test_v1_rows_w_and_g1(mannequin, orc):
+    from nlos_surface_optimization_amd import renderer_v1
+    v, f = mannequin
+    origin, normal = grid_sources(3, 0.3)
+    lb, ub, res, ns = 0.0, 2.4576, 2.4e-3, 6000
+    Tn = 1024
+    rs = np.random.RandomState(7)
+    base, _ = orc.render_transient(origin, normal, v, f, ns, lb, ub, res, accel=1)
+    data = base * (1 + 0.3 * rs.standard_normal(base.shape))
+    for w_width in (0, 3):
+        tr, path, grad = np.zeros((9, Tn)), np.zeros(Tn), np.full((v.shape[0], 3), 7.0)   # v1 zeroes the output
+        renderer_v1.renderStreamedGradient(origin, normal, v, f, ns, lb, ub, res, w_width, tr, path, grad, data)
+        t_o, g_o, p_o = orc.render_gradient_v1(origin, normal, v, f, ns, lb, ub, res, data, w_width, accel=1)
+        assert rel_l2(tr, t_o) <= 1e-5 and rel_l2(grad, g_o) <= 1e-4 and np.array_equal(path, p_o)
+    # v1 forward: unclamped form factor
+    tr = np.zeros((9, Tn))
+    renderer_v1.renderStreamedTransient(origin, normal, v, f, ns, lb, ub, res, tr, path)
+    t_o, _ = orc.render_transient(origin, normal, v, f, ns, lb, ub, res, clamp=0, accel=1)
+    assert rel_l2(tr, t_o) <= 1e-5
+
+
+def test_single_vertex_gradient(cfg1, orc):
+    from nlos_surface_optimization_amd import renderer
+    c = cfg1
+    o, n = c["origin"][:1], c["normal"][:1]
+    for vert in (0, 2):
+        grad = np.zeros((64, 3))
+        renderer.renderStreamedVertexGradient(o, n, c["v"], c["f"], 256, c["lb"], c["ub"], c["res"], grad, vert, 10, 1)
+        ref = orc.render_vertex_gradient(vert, o, n, c["v"], c["f"], 256, c["lb"], c["ub"], c["res"], refine=10, sigma_bin=1)
+        assert rel_l2(grad, ref) <= 1e-5 and np.abs(ref).max() > 0
+
+
+def test_facade_inverse_and_forward_rendering(bunny, orc):
+    import types
+    from nlos_surface_optimization_amd import rendering
+    v, f, origin, normal, ns = _setup(bunny)
+    opt = types.SimpleNamespace(lighting=origin, lighting_normal=normal, sample_num=ns, max_distance_bin=1200,
+                                distance_resolution=1.2e-3, bin_refine_resolution=10, sigma_bin=1, testing_flag=1,
+                                loss_flag=0, alpha_flag=0, albedo_flag=0, jitter=0, normal='fn')
+    mesh = types.SimpleNamespace(v=v, f=f)
+    t_fwd, path = rendering.forwardRendering(mesh, opt)
+    ub = opt.max_distance_bin * opt.distance_resolution
+    t_o, p_o = orc.render_transient(origin, normal, v, f, ns, 0, ub, 1.2e-3, accel=1)
+    assert t_fwd.shape == (4, 1200) and rel_l2(t_fwd, t_o) <= 1e-5 and np.array_equal(path, p_o)
+    data = t_o * 1.1
+    weight = rendering.create_weighting_function(data, 1)
+    tr, grad, _ = rendering.inverseRendering(mesh, data, weight, opt)
+    _, g_o, _ = orc.render_gradient(origin, normal, v, f, ns, 0, ub, 1.2e-3, data, weight, accel=1)
+    assert rel_l2(grad, g_o) <= 1e-4
+    # the reference's optimiser coupling (exp_bunny/test.py:212-214) runs unchanged
+    import torch
+    p = torch.nn.Parameter(torch.from_numpy(v.copy()))
+    opt_adam = torch.optim.Adam([p], lr=1e-4)
+    p.grad = torch.zeros_like(p)
+    p.grad.data = torch.from_numpy(grad).float()
+    opt_adam.step()
+    assert torch.isfinite(p).all() and not torch.equal(p.detach(), torch.from_numpy(v))
+
+
+def test_device_tensor_path_sharding_and_autograd(bunny, orc):
+    import torch
+    from nlos_surface_optimization_amd import device as nd
+    from nlos_surface_optimization_amd.dist import shard_bounds
+    v, f = bunny
+    origin, normal = grid_sources(3, 0.2)
+    ns = 9000
+    dev = torch.device("cuda", 0)
+    r = nd.TransientRenderer(dev)
+    tv, tf = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
+    to, tn = torch.from_numpy(origin).to(dev), torch.from_numpy(normal).to(dev)
+    rs = np.random.RandomState(9)
+    t_o, _ = orc.render_transient(origin, normal, v, f, ns, LB, UB, RES, accel=1)
+    data = t_o * (1 + 0.3 * rs.standard_normal(t_o.shape))
+    w = 0.5 + rs.random_sample(t_o.shape)
+    td, tw = torch.from_numpy(data).to(dev), torch.from_numpy(w).to(dev)
+    tr, grad, path = r.render_gradient(to, tn, tv, tf, ns, LB, UB, RES, data=td, weight=tw)
+    _, g_o, _ = orc.render_gradient(origin, normal, v, f, ns, LB, UB, RES, data, w, accel=1)
+    assert rel_l2(tr.cpu().numpy(), t_o) <= 1e-5 and rel_l2(grad.cpu().numpy(), g_o) <= 1e-4
+    # two source blocks (as two ranks would render them) == one render
+    gsum = torch.zeros_like(grad)
+    rows = []
+    for rank in range(2):
+        lo, hi = shard_bounds(9, rank, 2)
+        t, g, _ = r.render_gradient(to[lo:hi].contiguous(), tn[lo:hi].contiguous(), tv, tf, ns, LB, UB, RES,
+                                    data=td[lo:hi].contiguous(), weight=tw[lo:hi].contiguous(), source_offset=lo,
+                                    total_sources=9)
+        rows.append(t)
+        gsum += g
+    assert torch.equal(torch.cat(rows), tr)
+    assert rel_l2(gsum.cpu().numpy(), grad.cpu().numpy()) <= 1e-12
+    # autograd: d/dv of sum(w * (data - T)^2) / L equals the reference-style gradient
+    vp = tv.clone().requires_grad_(True)
+    T_ = nd.render_transient_autograd(r, vp, to, tn, tf, ns, LB, UB, RES, refine_scale=10, sigma_bin=1)
+    loss = (tw * (td - T_) ** 2).sum() / 9
+    loss.backward()
+    assert rel_l2(vp.grad.double().cpu().numpy(), g_o) <= 1e-4
+    assert r.scratch_bytes() > 0
+    r.close()
+
+
+def test_config2_size_properties(bunny):
+    """BASELINE config 2/3 size (32x32 sources, 512 bins, num_sample 20000): properties that need no oracle run.
+    (a) determinism of pass 1; (b) mass: sum_b transient == sum_f intensity; (c) the transient is linear in a
+    constant albedo and the gradient of an albedo-scaled scene scales accordingly; (d) a mesh translated along
+    the wall plane together with its sources gives the same transient (shift invariance)."""
+    import torch
+    from nlos_surface_optimization_amd import device as nd
+    v, f = bunny
+    origin, normal = grid_sources(32, 0.25)
+    dev = torch.device("cuda", 0)
+    r = nd.TransientRenderer(dev)
+    tv, tf = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
+    to, tn = torch.from_numpy(origin).to(dev), torch.from_numpy(normal).to(dev)
+    ns = 20000
+    t1, _ = r.render_transient(to, tn, tv, tf, ns, LB, UB, RES)
+    t2, _ = r.render_transient(to, tn, tv, tf, ns, LB, UB, RES)
+    assert t1.shape == (1024, 512) and float(t1.sum()) > 0
+    assert float((t1 - t2).abs().max()) <= 1e-15 * float(t1.max())          # (a) only fp64 add order may differ
+    inten = r.render_intensity(to, tn, tv, tf, ns, LB, UB)
+    assert abs(float(inten.sum()) - float(t1.sum())) <= 1e-10 * float(t1.sum())   # (b)
+    alb = torch.full((v.shape[0],), 0.5, dtype=torch.float32, device=dev)
+    ta, _ = r.render_transient(to, tn, tv, tf, ns, LB, UB, RES, albedo=alb)
+    assert float((ta - 0.5 * t1).abs().max()) <= 1e-6 * float(t1.max())           # (c) fp32 products
+    shift = torch.tensor([0.125, -0.0625, 0.0], device=dev)                         # exactly representable
+    ts, _ = r.render_transient((to + shift).contiguous(), tn, (tv + shift).contiguous(), tf, ns, LB, UB, RES)
+    assert float((ts - t1).abs().sum()) <= 2e-3 * float(t1.abs().sum())            # (d) up to fp32 rounding at bin edges
+    # gradient: every vertex touched by a lit face receives a finite gradient; total is translation-consistent
+    data = torch.zeros_like(t1)
+    w = torch.ones_like(t1)
+    _, g, _ = r.render_gradient(to, tn, tv, tf, ns, LB, UB, RES, data=data, weight=w)
+    assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    # data == 0 -> loss = sum T^2 / L; moving the object away from the wall (dz > 0) lowers it: <g, e_z> < 0
+    assert float(g[:, 2].sum()) < 0
+    r.close()

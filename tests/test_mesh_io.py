@@ -1,0 +1,29 @@
+import os
+
+import numpy as np
+
+from conftest import GOLDEN
+
+
+def test_obj_roundtrip_and_decimation_is_deterministic(tmp_path, bunny):
+    from nlos_surface_optimization_amd import mesh_io
+    v, f = bunny
+    p = os.path.join(str(tmp_path), "m.obj")
+    mesh_io.write_obj(p, v, f)
+    v2, f2 = mesh_io.read_obj(p)
+    assert np.array_equal(f, f2) and np.allclose(v, v2, rtol=0, atol=1e-7)
+    a = mesh_io.cluster_decimate(v, f, 0.02)
+    b = mesh_io.cluster_decimate(v, f, 0.02)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert 0 < a[1].shape[0] < f.shape[0]
+    assert a[1].min() >= 0 and a[1].max() < a[0].shape[0]
+    # winding preserved: outward normals -> positive signed volume
+    c = a[0].mean(0)
+    p0, p1, p2 = (a[0][a[1][:, k]].astype(np.float64) - c for k in range(3))
+    assert np.einsum("ij,ij->i", p0, np.cross(p1, p2)).sum() > 0
+
+
+def test_fixture_meshes_are_wall_facing_closed_enough(bunny, mannequin):
+    for v, f in (bunny, mannequin):
+        assert f.min() >= 0 and f.max() < v.shape[0]
+        assert v[:, 2].min() > 0.2          # in front of the wall z = 0

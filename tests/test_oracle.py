@@ -1,0 +1,263 @@
+"""CPU tests of the oracle (the checker itself): pinned against
+  (1) fixtures produced by the reference's own numpy prototype (imported from /root/reference
+      in the build container by tests/golden/make_golden.py; only numeric data is committed),
+  (2) finite differences of its own forward model (formula check),
+  (3) its committed golden vectors (regression pin for the GPU parity tests).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, grid_sources, rel_l2
+
+
+def test_counter_rng_is_pure_and_in_unit_interval(orc):
+    s = [orc.sample(7, k) for k in range(2000)]
+    a = np.array(s)
+    assert a.min() >= 0.0 and a.max() < 1.0
+    assert orc.sample(7, 123) == orc.sample(7, 123)
+    assert orc.sample(7, 123) != orc.sample(8, 123)
+    # 23-bit mantissa floats: k * 2^-23 exactly (stratified_transient_raytracer/rng_sse.h:33-42)
+    assert np.all(a * 2 ** 23 == np.round(a * 2 ** 23))
+    assert abs(a.mean() - 0.5) < 0.02
+
+
+def test_num_bins_is_float32_ceil(orc):
+    assert orc.num_bins(0.0, 2.0, 2.0 ** -5) == 64
+    assert orc.num_bins(0.625, 1.625, 2.0 ** -9) == 512
+    for T in (512, 1024, 1200, 2048):
+        assert orc.num_bins(0.0, float(np.float32(T) * np.float32(1.2e-3)), 1.2e-3) == T
+
+
+def test_closest_hit_matches_reference_prototype(orc):
+    """Hit selection, distance, binning and cos/d^2 weighting of the reference's numpy
+    prototype (transient_rendering_python/rendering.py:8-93) reproduced from the oracle's
+    closest-hit primitive on the prototype's own inputs."""
+    g = np.load(os.path.join(GOLDEN, "pyref_angular.npz"))
+    for name in ("plane", "toy"):
+        v, f, d = g[name + "_v"], g[name + "_f"], g[name + "_dir"]
+        nbin, res = int(g[name + "_nbin"]), float(g[name + "_res"])
+        fn = g[name + "_fn"]
+        for k, p in enumerate(g[name + "_pairs"]):
+            o = np.tile(p, (d.shape[0], 1))
+            hit = orc.intersect(o, d, v, f, accel=0)
+            prim = hit[:, 0].astype(int)
+            assert np.array_equal(prim, g[name + "_prim"][k])          # same nearest triangle per ray
+            ok = prim >= 0
+            bary = hit.copy()
+            pts = orc.barycentric_to_world(v, f, bary).astype(np.float64)
+            d1 = np.linalg.norm(pts[ok] - p, axis=1)
+            assert np.allclose(d1, g[name + "_tnear"][k][ok], rtol=0, atol=2e-6)   # unit directions: t == distance
+            # confocal pair: d2 == d1, v2 = (sensor - x)/d2; prototype's bin and weight
+            v2 = (p - pts[ok]) / d1[:, None]
+            cos = np.einsum("ij,ij->i", fn[prim[ok]], v2)
+            cos[cos < 0] = 0
+            b = np.ceil((d1 + d1) / res) - 1
+            keep = b <= nbin
+            t = np.zeros(nbin)
+            np.add.at(t, b[keep].astype(int), (cos / d1 ** 2)[keep])
+            t *= 2 * np.pi / d.shape[0]
+            ref = g[name + "_transient"][k]
+            # fp32 hit points vs the prototype's fp64: a sample may cross a bin edge
+            assert abs(t.sum() - ref.sum()) <= 1e-5 * ref.sum()
+            assert np.abs(np.cumsum(t) - np.cumsum(ref)).max() <= 2.0 * (cos / d1 ** 2).max() * 2 * np.pi / d.shape[0]
+
+
+def test_bvh_equals_brute_force_on_random_rays(orc, bunny):
+    v, f = bunny
+    rs = np.random.RandomState(5)
+    n = 20000
+    o = np.zeros((n, 3), np.float32)
+    o[:, :2] = rs.uniform(-0.3, 0.3, (n, 2))
+    tgt = v[rs.randint(0, v.shape[0], n)] + rs.normal(0, 0.01, (n, 3)).astype(np.float32)
+    d = (tgt - o).astype(np.float32)
+    a = orc.intersect(o, d, v, f, accel=0)
+    b = orc.intersect(o, d, v, f, accel=1)
+    assert np.array_equal(np.nan_to_num(a, nan=-7), np.nan_to_num(b, nan=-7))
+    assert (a[:, 0] >= 0).mean() > 0.5
+    s = orc.intersect(o, d, v, f, accel=1, short=True)
+    assert np.array_equal(s, a[:, 0])
+
+
+def test_render_bvh_equals_brute_force(orc, bunny):
+    v, f = bunny
+    origin, normal = grid_sources(2, 0.2)
+    a, _ = orc.render_transient(origin, normal, v, f, 9000, 0.625, 1.625, 2.0 ** -9, accel=0, threads=1)
+    b, _ = orc.render_transient(origin, normal, v, f, 9000, 0.625, 1.625, 2.0 ** -9, accel=1, threads=1)
+    assert np.array_equal(a, b)
+    assert a.sum() > 0
+
+
+def test_oracle_regression_vs_golden(orc, cfg1, bunny):
+    c = cfg1
+    g = np.load(os.path.join(GOLDEN, "oracle_cfg1.npz"))
+    tr, gr, path = orc.render_gradient(c["origin"], c["normal"], c["v"], c["f"], 256, c["lb"], c["ub"], c["res"],
+                                       np.zeros((4, 64)), np.ones((4, 64)), seed=0)
+    assert rel_l2(tr, g["transient"]) < 1e-13 and rel_l2(gr, g["gradient"]) < 1e-12
+    assert np.array_equal(path, g["pathlengths"])
+    # plane 2h in [0.76, 1.60] -> bins 24..51
+    nz = np.nonzero(tr.sum(axis=0))[0]
+    assert nz.min() >= 24 and nz.max() <= 51
+    v, f = bunny
+    g = np.load(os.path.join(GOLDEN, "oracle_bunny16.npz"))
+    tr, gr, _ = orc.render_gradient(g["origin"], g["normal"], v, f, int(g["num_sample"]), float(g["lb"]),
+                                    float(g["ub"]), float(g["res"]), g["data"], g["weight"], seed=0, accel=1)
+    assert rel_l2(tr, g["transient"]) < 1e-13 and rel_l2(gr, g["gradient"]) < 1e-11
+
+
+def test_flipped_plane_is_dark(orc, cfg1):
+    c = cfg1
+    tr, _ = orc.render_transient(c["origin"], c["normal"], c["v"], np.ascontiguousarray(c["f"][:, [0, 2, 1]]), 256,
+                                 c["lb"], c["ub"], c["res"])
+    assert np.all(tr == 0)
+    # v1 forward has no clamp: back faces contribute ff^2
+    tr1, _ = orc.render_transient(c["origin"], c["normal"], c["v"], np.ascontiguousarray(c["f"][:, [0, 2, 1]]), 256,
+                                  c["lb"], c["ub"], c["res"], clamp=0)
+    tr2, _ = orc.render_transient(c["origin"], c["normal"], c["v"], c["f"], 256, c["lb"], c["ub"], c["res"])
+    # (the flipped winding permutes the stratified sample map, so only the mass is comparable)
+    assert tr1.sum() > 0 and abs(tr1.sum() - tr2.sum()) < 0.25 * tr2.sum()
+
+
+def test_source_sharding_is_exact(orc, bunny):
+    v, f = bunny
+    origin, normal = grid_sources(3, 0.2)
+    kw = dict(refine=10, sigma_bin=1, accel=1, threads=1)
+    rs = np.random.RandomState(0)
+    data = rs.random_sample((9, 512)) * 1e-3
+    w = np.ones((9, 512))
+    t_all, g_all, _ = orc.render_gradient(origin, normal, v, f, 8000, 0.625, 1.625, 2.0 ** -9, data, w, **kw)
+    g_sum = np.zeros_like(g_all)
+    rows = []
+    for lo, hi in ((0, 4), (4, 9)):
+        t, g, _ = orc.render_gradient(origin[lo:hi], normal[lo:hi], v, f, 8000, 0.625, 1.625, 2.0 ** -9,
+                                      data[lo:hi], w[lo:hi], source_offset=lo, total_sources=9, **kw)
+        rows.append(t)
+        g_sum += g
+    assert np.array_equal(np.vstack(rows), t_all)
+    assert rel_l2(g_sum, g_all) < 1e-13
+
+
+def test_gradient_formula_against_finite_differences(orc):
+    """With the normal term on and a large refine_scale the analytic gradient converges to the
+    finite-difference gradient of the Gaussian-smoothed loss.  sigma_bin >= 5
+    makes the forward transient use the same Gaussian as the gradient taps, so
+    loss(v) = (1/L) sum w (data - T(v))^2 is exactly what the gradient differentiates."""
+    v = np.array([[-.11, -.07, .42], [.12, -.09, .47], [.02, .13, .40]], np.float32)
+    f = np.array([[0, 2, 1]], np.int32)
+    origin = np.array([[0.05, -0.02, 0], [-0.15, 0.1, 0]], np.float32)
+    normal = np.tile(np.array([0, 0, 1], np.float32), (2, 1))
+    lb, ub, res, ns = 0.5, 1.5, 2.0 ** -6, 64
+    R, SB = 24, 5
+    rs = np.random.RandomState(2)
+    data = rs.random_sample((2, 64)) * 0.02
+    w = 0.5 + rs.random_sample((2, 64))
+
+    def loss(vv):
+        t, _ = orc.render_transient(origin, normal, vv, f, ns, lb, ub, res, refine=R, sigma_bin=SB, threads=1)
+        return float(np.sum(w * (data - t) ** 2) / origin.shape[0])
+
+    _, g, _ = orc.render_gradient(origin, normal, v, f, ns, lb, ub, res, data, w, refine=R, sigma_bin=SB,
+                                  testing_flag=0, normal_term=1, threads=1)
+    _, g_off, _ = orc.render_gradient(origin, normal, v, f, ns, lb, ub, res, data, w, refine=R, sigma_bin=SB,
+                                      testing_flag=0, normal_term=0, threads=1)
+    fd = np.zeros((3, 3))
+    eps = 1e-3          # the reference's own step (paper_fig/finite_diff.py:86-98); smaller steps resolve the sub-bin staircase
+    for i in range(3):
+        for c in range(3):
+            vp, vm = v.astype(np.float64).copy(), v.astype(np.float64).copy()
+            vp[i, c] += eps
+            vm[i, c] -= eps
+            fd[i, c] = (loss(vp.astype(np.float32)) - loss(vm.astype(np.float32))) / (
+                float(np.float32(vp[i, c])) - float(np.float32(vm[i, c])))
+    err_on, err_off = rel_l2(g, fd), rel_l2(g_off, fd)
+    assert err_on < 0.03, (err_on, err_off)
+    assert err_on < err_off      # dropping the normal term (v2 default for face normals) is further from FD
+
+
+def test_scalar_gradients_against_finite_differences(orc, cfg1):
+    c = cfg1
+    rs = np.random.RandomState(4)
+    data = rs.random_sample((4, 64)) * 0.3
+    w = np.ones((4, 64))
+    kw = dict(refine=10, sigma_bin=5, threads=1)
+    V = c["v"].shape[0]
+
+    def loss_alb(a):
+        t, _ = orc.render_transient(c["origin"], c["normal"], c["v"], c["f"], 256, c["lb"], c["ub"], c["res"],
+                                    refine=10, sigma_bin=5, albedo=np.full(V, a, np.float32), threads=1)
+        return float(np.sum(w * (data - t) ** 2) / 4)
+
+    _, ga = orc.render_gradient_scalar(c["origin"], c["normal"], c["v"], c["f"], 256, c["lb"], c["ub"], c["res"],
+                                       data, w, albedo=np.full(V, 0.8, np.float32), **kw)
+    fd = (loss_alb(0.81) - loss_alb(0.79)) / (float(np.float32(0.81)) - float(np.float32(0.79)))
+    assert abs(ga - fd) <= 0.02 * abs(fd)
+
+    def loss_alpha(al):
+        t, _ = orc.render_transient(c["origin"], c["normal"], c["v"], c["f"], 256, c["lb"], c["ub"], c["res"],
+                                    refine=10, sigma_bin=5, ggx_alpha=al, threads=1)
+        return float(np.sum(w * (data - t) ** 2) / 4)
+
+    _, gal = orc.render_gradient_scalar(c["origin"], c["normal"], c["v"], c["f"], 256, c["lb"], c["ub"], c["res"],
+                                        data, w, wrt_alpha=True, ggx_alpha=0.3, **kw)
+    fd = (loss_alpha(0.305) - loss_alpha(0.295)) / (float(np.float32(0.305)) - float(np.float32(0.295)))
+    assert abs(gal - fd) <= 0.03 * abs(fd)
+
+
+def test_ggx_table_and_derivatives(orc):
+    g = np.load(os.path.join(GOLDEN, "ggx_table.npz"))
+    n = np.array([0, 0, 1], np.float32)
+    for i, a in enumerate(g["alpha"]):
+        for j, c in enumerate(g["nw"]):
+            s = np.sqrt(max(0.0, 1.0 - float(c) ** 2))
+            w = np.array([s, 0, c], np.float32)
+            assert orc.ggx(a, n, w, "eval") == g["eval"][i, j]
+            assert orc.ggx(a, n, w, "adiff") == g["adiff"][i, j]
+            assert orc.ggx(a, n, w, "nwsdiff") == g["nwsdiff"][i, j]
+    # early-outs (ggx_confocal.cpp:15-17): back side is black
+    assert np.all(g["eval"][:, g["nw"] <= 0] == 0)
+    # d/d alpha against finite differences of eval
+    w = np.array([0.6, 0, 0.8], np.float32)
+    for a in (0.2, 0.4, 0.7):
+        fd = (orc.ggx(a + 1e-3, n, w) - orc.ggx(a - 1e-3, n, w)) / 2e-3
+        assert abs(orc.ggx(a, n, w, "adiff") - fd) <= 2e-2 * abs(fd)
+
+
+def test_v1_residual_box_filter_and_shapes(orc, cfg1):
+    c = cfg1
+    rs = np.random.RandomState(6)
+    data = rs.random_sample((4, 64)) * 0.2
+    t0, g0, _ = orc.render_gradient_v1(c["origin"], c["normal"], c["v"], c["f"], 256, c["lb"], c["ub"], c["res"], data, 0)
+    t2, g2, _ = orc.render_gradient_v1(c["origin"], c["normal"], c["v"], c["f"], 256, c["lb"], c["ub"], c["res"], data, 2)
+    assert np.array_equal(t0, t2) and g0.shape == (4, 3)
+    assert rel_l2(g0, g2) > 1e-3          # smoothing the residual changes the gradient
+    # with w_width = 0 v1 == v2 kernel with one unit tap and the normal term on: compare to the v2
+    # oracle at sigma_bin -> tiny kernel is not available, so check the symmetric structure instead
+    assert np.all(np.isfinite(g0)) and np.abs(g0).max() > 0
+
+
+def test_intensity_equals_row_mass(orc, bunny):
+    """sum_f intensity[f] == sum_{l,b} transient[l,b]: same samples, same acceptance, no binning."""
+    v, f = bunny
+    origin, normal = grid_sources(2, 0.2)
+    t, _ = orc.render_transient(origin, normal, v, f, 9000, 0.625, 1.625, 2.0 ** -9, accel=1)
+    inten = orc.render_intensity(origin, normal, v, f, 9000, 0.625, 1.625, accel=1)
+    assert abs(inten.sum() - t.sum()) <= 1e-12 * t.sum()
+
+
+def test_vertex_gradient_sums_to_full_gradient_structure(orc, cfg1):
+    """The single-vertex per-bin gradient (paper_fig/finite_diff.py) contracted with -2*diff equals
+    the corresponding row of the full vertex gradient when both use the normal term."""
+    c = cfg1
+    rs = np.random.RandomState(8)
+    data = rs.random_sample((1, 64)) * 0.3
+    w = np.ones((1, 64))
+    o, n = c["origin"][:1], c["normal"][:1]
+    t, g, _ = orc.render_gradient(o, n, c["v"], c["f"], 256, c["lb"], c["ub"], c["res"], data, w, refine=10,
+                                  sigma_bin=1, normal_term=1, threads=1)
+    diff = (data - t) * w
+    for vert in range(4):
+        pv = orc.render_vertex_gradient(vert, o, n, c["v"], c["f"], 256, c["lb"], c["ub"], c["res"], refine=10,
+                                        sigma_bin=1, threads=1)
+        contracted = (-2 * diff[0][:, None] * pv).sum(axis=0)
+        assert np.allclose(contracted, g[vert], rtol=2e-5, atol=1e-9 * np.abs(g).max())
