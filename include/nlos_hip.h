@@ -200,6 +200,8 @@ typedef struct nlos_render_args {
     int32_t keep_visibility;    /* TRANSIENT: also record the per-sample visibility cache */
     int32_t reuse_visibility;   /* GRADIENT with residual: skip pass 1, reuse the cache recorded by the
                                    previous render on this ctx (same mesh, sources, samples, seed) */
+    int32_t force_bvh;          /* 1: occlusion by BVH traversal only (default 0: per-source perspective
+                                   grid in LDS when the mesh fits, BVH otherwise; identical results) */
 } nlos_render_args;
 
 int  nlos_sizeof_render_args(void);                 /* for FFI layout checks */

@@ -63,6 +63,7 @@ class RenderArgs(ctypes.Structure):
         ("residual", ctypes.c_void_p),
         ("keep_visibility", ctypes.c_int32),
         ("reuse_visibility", ctypes.c_int32),
+        ("force_bvh", ctypes.c_int32),
     ]
 
 

@@ -119,10 +119,24 @@ int get_default_ctx(nlos_ctx** out) {
 // Gaussian taps of the gradient pass, computed exactly as the reference does
 // (smoothed_transient/transient_and_gradient.cpp:537-547, :973-974): K =
 // 4*refine*sigma_bin+1, sigma = res*sigma_bin/2.355 (float*int, then double),
-// delta_i evaluated in float.  Layout: [w(K) | delta(K) | g(K)].
+// delta_i evaluated in float.  Layout: [w(K) | delta(K) | g(K) | P0(K+1) | P1(K+1)] with the
+// prefix sums the grouped-tap gradient kernel uses.
+void host_prefix(std::vector<double>& t, int K) {
+    double p0 = 0.0, p1 = 0.0;
+    t[3 * (size_t)K] = 0.0;
+    t[4 * (size_t)K + 1] = 0.0;
+    for (int i = 0; i < K; ++i) {
+        double wf = (double)(float)t[i];
+        p0 += wf;
+        p1 += t[2 * (size_t)K + i] * wf;
+        t[3 * (size_t)K + 1 + i] = p0;
+        t[4 * (size_t)K + 2 + i] = p1;
+    }
+}
+
 void host_taps(int refine, int sigma_bin, float res, std::vector<double>& t) {
     const int K = 4 * refine * sigma_bin + 1;
-    t.assign(3 * (size_t)K, 0.0);
+    t.assign(5 * (size_t)K + 2, 0.0);
     const double sigma = res * sigma_bin / 2.355;
     const double sigma_square = sigma * sigma;
     const double normalization = 1 / sigma / std::sqrt(2 * M_PI) * res / refine;
@@ -134,12 +148,14 @@ void host_taps(int refine, int sigma_bin, float res, std::vector<double>& t) {
         t[K + i] = dl;
         t[2 * K + i] = (double)(float)(dl / sigma_square * 2);
     }
+    host_prefix(t, K);
 }
 
 // single unit tap (v1 gradient: delta 0, weight 1)
 void host_taps_unit(std::vector<double>& t) {
-    t.assign(3, 0.0);
+    t.assign(7, 0.0);
     t[0] = 1.0;
+    host_prefix(t, 1);
 }
 
 int ensure_taps(nlos_ctx* c, int kind, int refine, int sigma_bin, float res, hipStream_t st, int* K_out) {
@@ -401,6 +417,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.sp.nbins = rb;
     fa.vis = nullptr; fa.vis_words = vis_words;
     fa.intensity = a->intensity; fa.mode_intensity = mode == NLOS_MODE_INTENSITY ? 1 : 0;
+    fa.force_bvh = a->force_bvh;
     fa.rows = nullptr;
     nlos_ctx::VisKey key;
     key.L = L; key.F = nF; key.V = nV; key.spt = spt; key.off = a->source_offset; key.seed = a->seed;
@@ -495,7 +512,11 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         ga.sp.res = res; ga.sp.nbins = T;
         ga.vis = c->vis.as<uint32_t>(); ga.vis_words = vis_words;
         ga.tap_w = c->taps.as<double>(); ga.tap_delta = ga.tap_w + K; ga.tap_g = ga.tap_w + 2 * K;
+        ga.tap_p0 = ga.tap_w + 3 * K; ga.tap_p1 = ga.tap_w + 4 * K + 1;
         ga.K = K;
+        const bool v1 = mode == NLOS_MODE_GRADIENT_V1;
+        ga.two_rs = v1 ? 0 : 2 * a->refine_scale * a->sigma_bin;
+        ga.r_over_res = v1 ? 1.0 : (double)a->refine_scale / (double)res;
         ga.v1_style = mode == NLOS_MODE_GRADIENT_V1 ? 1 : 0;
         ga.vertex_num = a->vertex_num;
         ga.diff = diff_ptr;
@@ -523,7 +544,8 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
                 ga.diff = transient;   // unused by mode 3; any valid [L,T] buffer
                 break;
         }
-        ga.lds_grad = (ga.mode == 0 && 3 * (size_t)nV * sizeof(double) + (size_t)T * sizeof(double) + 64 <= (size_t)nlos::kGradLdsBudget) ? 1 : 0;
+        ga.lds_grad = (ga.mode == 0 && (3 * (size_t)nV + (size_t)T + 3 * (size_t)K + 2) * sizeof(double) + 64 <=
+                                           (size_t)nlos::kGradLdsBudget) ? 1 : 0;
         nlos::launch_gradient(ga, st);
     }
     mark(c, 4, st);

@@ -66,6 +66,7 @@ struct ForwardArgs {
     int vis_words;
     double* intensity;       // [F] (mode intensity: accumulated with atomics; rows unused)
     int mode_intensity;
+    int force_bvh;           // 1: never use the per-source perspective grid (tests / large meshes)
 };
 void launch_forward(const ForwardArgs& a, hipStream_t stream);
 
@@ -103,7 +104,11 @@ struct GradientArgs {
     const double* tap_w;     // [K] weighting_kernal
     const double* tap_delta; // [K] delta_length (float-evaluated, widened)
     const double* tap_g;     // [K] (float)(delta/sigma^2*2) widened
+    const double* tap_p0;    // [K+1] prefix sums of (double)(float)w
+    const double* tap_p1;    // [K+1] prefix sums of g * (double)(float)w
     int K;
+    int two_rs;              // 2*refine*sigma_bin (index of the centre tap)
+    double r_over_res;       // refine / resolution
     int normal_term;         // 0/1 (already resolved)
     int v1_style;            // 1: G1 (t1 without albedo)
     int mode;                // 0 vertex gradient [V,3], 1 scalar albedo, 2 scalar alpha, 3 single vertex per bin

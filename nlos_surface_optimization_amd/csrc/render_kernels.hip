@@ -31,6 +31,9 @@
 #include "nlos_device.h"
 #include "nlos_kernels.h"
 
+#include <algorithm>
+#include <cmath>
+
 namespace nlos {
 
 namespace {
@@ -115,7 +118,75 @@ __device__ __forceinline__ int wave_ticket(int* counter) {
 }
 
 // ------------------------------------------------------------------- forward
-template <int FEAT>
+// Packet occlusion query.  The CH rays of a chunk leave the same wall point towards the same
+// small triangle, so one traversal serves all of them: a node is entered when its (padded) box
+// meets the pyramid  { o + s*(mx, my, 1) : mx in [mxlo,mxhi], my in [mylo,myhi], 0 <= s <= zmax }
+// spanned by the rays' slopes dx/dz, dy/dz and the deepest own-face hit.  Every point of every ray
+// segment lies in that pyramid, so no occluder can be missed; leaves run the exact per-ray
+// triangle test.  Requires dz > 0 for all rays (the wall faces the scene); the caller falls back
+// to the per-ray traversal otherwise.  Returns the still-unoccluded subset of `alive`.
+template <int CH>
+__device__ __forceinline__ uint32_t trace_packet(const float4* __restrict__ nodes, int n_nodes,
+                                                 const float4* __restrict__ tris,
+                                                 const int* __restrict__ face_id, V3 o,
+                                                 const float (&dx)[CH], const float (&dy)[CH],
+                                                 const float (&dz)[CH], const float (&ts)[CH],
+                                                 uint32_t alive, int self, int self_fid) {
+    const float big = 3.0e38f;
+    float mxlo = big, mxhi = -big, mylo = big, myhi = -big, zmax = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        if (alive & (1u << c)) {
+            float iz = 1.0f / dz[c];
+            float mx = dx[c] * iz, my = dy[c] * iz;
+            mxlo = fminf(mxlo, mx); mxhi = fmaxf(mxhi, mx);
+            mylo = fminf(mylo, my); myhi = fmaxf(myhi, my);
+            zmax = fmaxf(zmax, ts[c] * dz[c]);
+        }
+    }
+    // a few ulp of slack on top of the build-time box padding
+    mxlo -= 2e-6f * (1.0f + fabsf(mxlo)); mxhi += 2e-6f * (1.0f + fabsf(mxhi));
+    mylo -= 2e-6f * (1.0f + fabsf(mylo)); myhi += 2e-6f * (1.0f + fabsf(myhi));
+    zmax += 2e-6f * zmax;
+    int i = 0;
+    while (i < n_nodes && alive) {
+        int leaf = -1;
+        while (i < n_nodes) {
+            const float4 a = nodes[2 * i], b = nodes[2 * i + 1];
+            const float za = fmaxf(a.z - o.z, 0.0f);
+            const float zb = fminf(b.y - o.z, zmax);
+            const float fxlo = fminf(za * mxlo, zb * mxlo), fxhi = fmaxf(za * mxhi, zb * mxhi);
+            const float fylo = fminf(za * mylo, zb * mylo), fyhi = fmaxf(za * myhi, zb * myhi);
+            const bool hit = (za <= zb) && (a.x - o.x <= fxhi) && (a.w - o.x >= fxlo) &&
+                             (a.y - o.y <= fyhi) && (b.x - o.y >= fylo);
+            const int esc = __float_as_int(b.z);
+            const int tri = __float_as_int(b.w);
+            if (hit && tri >= 0) { leaf = tri; i = esc; break; }
+            i = hit ? i + 1 : esc;
+        }
+        if (leaf >= 0 && leaf != self) {
+            const Tri tr = load_tri(tris, leaf);
+            int lfid = -1;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (alive & (1u << c)) {
+                    float t, u, v;
+                    if (tri_test(tr, o, mk(dx[c], dy[c], dz[c]), t, u, v)) {
+                        bool occ = t < ts[c];
+                        if (!occ && t == ts[c]) {
+                            if (lfid < 0) lfid = face_id[leaf];
+                            occ = lfid < self_fid;
+                        }
+                        if (occ) alive &= ~(1u << c);
+                    }
+                }
+            }
+        }
+    }
+    return alive;
+}
+
+template <int FEAT, int CH>
 __global__ __launch_bounds__(256) void k_forward(ForwardArgs a, int rows_in_lds) {
     // one dynamic LDS block: [ticket counter (8 B)][histogram row]; no static LDS in
     // front of it, so the doubles stay 8-byte aligned
@@ -156,32 +227,309 @@ __global__ __launch_bounds__(256) void k_forward(ForwardArgs a, int rows_in_lds)
         const uint64_t kbase = (lg * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
         uint32_t word = 0;
         double inten = 0.0;
+        for (int c0 = 0; c0 < spt; c0 += CH) {
+            float dx[CH], dy[CH], dz[CH], ts[CH], val[CH];
+            int bin[CH];
+            uint32_t alive = 0;
+            bool zmajor = true;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int s = c0 + c;
+                Geo g;
+                float t_self = 0.0f;
+                bool ok = s < spt;
+                if (ok)
+                    ok = sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, lb, ub, a.sc.vertex_normal,
+                                          a.sc.albedo, g, t_self);
+                float vv = 0.0f;
+                int bb = -1;
+                if (ok) {
+                    float ff = -dot(g.n, g.dir) * dot(on, g.dir) / g.h / g.h;
+                    if (a.sp.clamp) {
+                        ff = emax0(ff);
+                        ok = ff > 0.0f;      // zero contribution in both passes: never trace
+                    }
+                    vv = f.area * g.alb * ff * ff;
+                    if (FEAT & FEAT_GGX) vv = vv * ggx_eval(a.sp.ggx_alpha, dot(g.n, -g.dir));
+                    bb = (int)floorf((2.0f * g.h - lb) / res);
+                }
+                dx[c] = ok ? g.dir.x : 0.0f;
+                dy[c] = ok ? g.dir.y : 0.0f;
+                dz[c] = ok ? g.dir.z : 1.0f;
+                ts[c] = t_self;
+                val[c] = vv;
+                bin[c] = bb;
+                if (ok) {
+                    alive |= 1u << c;
+                    zmajor = zmajor && (g.dir.z >= 0.05f);
+                }
+            }
+            if (alive) {
+                if (zmajor) {
+                    alive = trace_packet<CH>(a.sc.nodes, a.sc.n_nodes, a.sc.tris, a.sc.face_id, o, dx, dy, dz, ts,
+                                             alive, j, f.fid);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+                        if ((alive & (1u << c)) &&
+                            occluded(a.sc.nodes, a.sc.n_nodes, a.sc.tris, a.sc.face_id, o, mk(dx[c], dy[c], dz[c]),
+                                     ts[c], j, f.fid))
+                            alive &= ~(1u << c);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (alive & (1u << c)) {
+                    if (a.mode_intensity) {
+                        inten += (double)val[c] / (double)spt;
+                    } else if (bin[c] >= 0 && bin[c] < nbins) {
+                        double cc = (double)val[c] / (double)spt;
+                        if (rows_in_lds) unsafeAtomicAdd(&s_row[bin[c]], cc);
+                        else unsafeAtomicAdd(&grow[bin[c]], cc);
+                    }
+                }
+            }
+            word |= alive << (c0 & 31);
+            if (((c0 + CH) & 31) == 0 || c0 + CH >= spt) {
+                if (visp) visp[(size_t)(c0 >> 5) * F] = word;
+                word = 0;
+            }
+        }
+        if (a.mode_intensity && inten != 0.0) unsafeAtomicAdd(&a.intensity[f.fid], inten);
+    }
+    if (rows_in_lds && grow) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nbins; i += blockDim.x) grow[i] = s_row[i];
+    }
+}
+
+// ------------------------------------------------------------- forward (grid)
+// Per-source perspective grid.  Every ray of a workgroup starts at the same wall point o, so the
+// triangles that can block the ray towards slope (mx, my) = (dx/dz, dy/dz) are exactly those whose
+// perspective projection from o covers that slope point.  The workgroup therefore rasterises all
+// F triangles (conservatively) into an R x R grid over slope space, held in LDS as a CSR
+// structure (counting pass, block scan, fill pass), and each ray tests only the triangles of its
+// own cell: no tree traversal, no per-lane stack, short and nearly uniform candidate loops.
+// Candidates that lie entirely deeper than the ray's own-face hit are rejected from their
+// z-extent before the triangle test.  The set of accepted samples is identical to the BVH path's
+// (the cell lists are a superset of every triangle the exact test could report).  Sources for
+// which the scene is not strictly in front of the wall point, or whose grid overflows its LDS
+// budget, fall back to the stackless BVH traversal.
+struct GridView {
+    float gx0, gy0, inv_cw, inv_ch;
+    int R;
+};
+
+__device__ __forceinline__ int cell_coord(float m, float g0, float inv_c, int R) {
+    int c = (int)floorf((m - g0) * inv_c);
+    return min(max(c, 0), R - 1);
+}
+
+// conservative rasterisation of the projection of triangle (p0,p1,p2) seen from o
+template <class Fn>
+__device__ __forceinline__ void raster_tri(const GridView& g, V3 o, V3 p0, V3 p1, V3 p2, Fn fn) {
+    const float iz0 = 1.0f / (p0.z - o.z), iz1 = 1.0f / (p1.z - o.z), iz2 = 1.0f / (p2.z - o.z);
+    const float ax = (p0.x - o.x) * iz0, ay = (p0.y - o.y) * iz0;
+    const float bx = (p1.x - o.x) * iz1, by = (p1.y - o.y) * iz1;
+    const float cx = (p2.x - o.x) * iz2, cy = (p2.y - o.y) * iz2;
+    const float cw = 1.0f / g.inv_cw, ch = 1.0f / g.inv_ch;
+    const float mgx = 1e-3f * cw, mgy = 1e-3f * ch;          // >> fp32 rounding of the projection
+    const int cx0 = cell_coord(fminf(fminf(ax, bx), cx) - mgx, g.gx0, g.inv_cw, g.R);
+    const int cx1 = cell_coord(fmaxf(fmaxf(ax, bx), cx) + mgx, g.gx0, g.inv_cw, g.R);
+    const int cy0 = cell_coord(fminf(fminf(ay, by), cy) - mgy, g.gy0, g.inv_ch, g.R);
+    const int cy1 = cell_coord(fmaxf(fmaxf(ay, by), cy) + mgy, g.gy0, g.inv_ch, g.R);
+    // edge functions, oriented so that the inside is >= 0
+    float area = (bx - ax) * (cy - ay) - (by - ay) * (cx - ax);
+    const float sgn = area < 0.0f ? -1.0f : 1.0f;
+    const bool thin = fabsf(area) < 1e-4f * cw * ch;         // edge-on: bbox cells only
+    const float A0 = -(by - ay) * sgn, B0 = (bx - ax) * sgn, C0 = -(A0 * ax + B0 * ay);
+    const float A1 = -(cy - by) * sgn, B1 = (cx - bx) * sgn, C1 = -(A1 * bx + B1 * by);
+    const float A2 = -(ay - cy) * sgn, B2 = (ax - cx) * sgn, C2 = -(A2 * cx + B2 * cy);
+    const float t0 = 2e-3f * (fabsf(A0) * cw + fabsf(B0) * ch);
+    const float t1 = 2e-3f * (fabsf(A1) * cw + fabsf(B1) * ch);
+    const float t2 = 2e-3f * (fabsf(A2) * cw + fabsf(B2) * ch);
+    for (int yy = cy0; yy <= cy1; ++yy) {
+        const float y0 = g.gy0 + (float)yy * ch, y1 = y0 + ch;
+        for (int xx = cx0; xx <= cx1; ++xx) {
+            const float x0 = g.gx0 + (float)xx * cw, x1 = x0 + cw;
+            bool in = true;
+            if (!thin) {
+                in = (A0 * (A0 > 0 ? x1 : x0) + B0 * (B0 > 0 ? y1 : y0) + C0 >= -t0) &&
+                     (A1 * (A1 > 0 ? x1 : x0) + B1 * (B1 > 0 ? y1 : y0) + C1 >= -t1) &&
+                     (A2 * (A2 > 0 ? x1 : x0) + B2 * (B2 > 0 ? y1 : y0) + C2 >= -t2);
+            }
+            if (in) fn(yy * g.R + xx);
+        }
+    }
+}
+
+template <int FEAT>
+__global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in_lds, int R, int cap) {
+    // dynamic LDS: [ctl: ticket, bad, total, pad (16 B)][row nbins f64][cells R*R+1 u32][entries cap u16]
+    extern __shared__ double s_lds[];
+    int* s_ctl = reinterpret_cast<int*>(s_lds);
+    double* s_row = s_lds + 2;
+    const int nbins = a.sp.nbins;
+    const int ncell = R * R;
+    uint32_t* s_cell = reinterpret_cast<uint32_t*>(s_row + (rows_in_lds ? nbins : 0));
+    uint16_t* s_ent = reinterpret_cast<uint16_t*>(s_cell + ncell + 1);
+    __shared__ uint32_t s_scan[512];
+
+    const int l = blockIdx.x;
+    const int F = a.sc.F;
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const V3 o = ld3(a.src.origin + 3 * (size_t)l);
+    const V3 on = ld3(a.src.normal + 3 * (size_t)l);
+
+    // ---- grid frame from the (padded) root box of the BVH: O(1) per source ------------------
+    const float4 ra = a.sc.nodes[0], rb = a.sc.nodes[1];
+    const float zr0 = ra.z - o.z, zr1 = rb.y - o.z;
+    const float ext = fmaxf(fmaxf(ra.w - ra.x, rb.x - ra.y), rb.y - ra.z);
+    const bool frame_ok = zr0 > 0.02f * ext && zr0 > 0.0f;
+    GridView g;
+    g.R = R;
+    {
+        const float i0 = 1.0f / fmaxf(zr0, 1e-30f), i1 = 1.0f / fmaxf(zr1, 1e-30f);
+        const float xl = ra.x - o.x, xh = ra.w - o.x, yl = ra.y - o.y, yh = rb.x - o.y;
+        float gx0 = fminf(xl * i0, xl * i1), gx1 = fmaxf(xh * i0, xh * i1);
+        float gy0 = fminf(yl * i0, yl * i1), gy1 = fmaxf(yh * i0, yh * i1);
+        const float wx = fmaxf(gx1 - gx0, 1e-12f), wy = fmaxf(gy1 - gy0, 1e-12f);
+        g.gx0 = gx0 - 1e-3f * wx;
+        g.gy0 = gy0 - 1e-3f * wy;
+        g.inv_cw = (float)R / (wx * 1.002f);
+        g.inv_ch = (float)R / (wy * 1.002f);
+    }
+
+    if (rows_in_lds)
+        for (int i = tid; i < nbins; i += NT) s_row[i] = 0.0;
+    for (int i = tid; i <= ncell; i += NT) s_cell[i] = 0u;
+    if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = frame_ok ? 0 : 1; s_ctl[2] = 0; }
+    __syncthreads();
+
+    if (frame_ok) {
+        // ---- counting pass ---------------------------------------------------------------------
+        for (int j = tid; j < F; j += NT) {
+            const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
+            raster_tri(g, o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x),
+                       [&](int c) { atomicAdd(&s_cell[c], 1u); });
+        }
+        __syncthreads();
+        // ---- exclusive scan of the cell counts (each thread owns a contiguous slice) -------------
+        const int per = (ncell + NT - 1) / NT;
+        const int c0 = min(tid * per, ncell), c1 = min(c0 + per, ncell);
+        uint32_t sum = 0;
+        for (int c = c0; c < c1; ++c) sum += s_cell[c];
+        s_scan[tid] = sum;
+        __syncthreads();
+        for (int off = 1; off < NT; off <<= 1) {
+            uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        uint32_t run = s_scan[tid] - sum;
+        for (int c = c0; c < c1; ++c) { uint32_t n = s_cell[c]; s_cell[c] = run; run += n; }
+        if (tid == NT - 1) { s_ctl[2] = (int)s_scan[tid]; if ((int)s_scan[tid] > cap) s_ctl[1] = 1; }
+        __syncthreads();
+        // ---- fill pass: s_cell[c] is the write cursor, afterwards the END of cell c ----------------
+        if (s_ctl[1] == 0) {
+            for (int j = tid; j < F; j += NT) {
+                const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
+                raster_tri(g, o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x),
+                           [&](int c) { uint32_t pos = atomicAdd(&s_cell[c], 1u); s_ent[pos] = (uint16_t)j; });
+            }
+        }
+        __syncthreads();
+    }
+    const bool use_grid = s_ctl[1] == 0;
+
+    // ---- trace + histogram ------------------------------------------------------------------------
+    const uint64_t lg = (uint64_t)(a.src.source_offset + l);
+    const int spt = a.sp.spt;
+    const float lb = a.sp.lb, ub = a.sp.ub, res = a.sp.res;
+    double* grow = a.rows ? a.rows + (size_t)l * nbins : nullptr;
+    const int nblocks = (F + 63) >> 6;
+    const int lane = tid & 63;
+
+    for (;;) {
+        const int b = wave_ticket(&s_ctl[0]);
+        if (b >= nblocks) break;
+        const int j = (b << 6) + lane;
+        if (j >= F) continue;
+        const Face f = load_face(a.sc.facerec, j);
+        uint32_t* visp = a.vis ? a.vis + ((size_t)l * a.vis_words) * F + j : nullptr;
+        bool dark = f.degenerate;
+        if (!dark && !(FEAT & FEAT_VN) && a.sp.clamp) {
+            // face-normal form factor: -dot(n,dir) has the sign of dist(o, plane(f)) for every sample of
+            // the face; if the wall point is clearly behind the face and the face is in front of the wall,
+            // every clamped form factor is exactly 0 -> nothing to sample, nothing to trace.
+            const float dist = dot(f.fn, o - f.p0);
+            const float sc = fabsf(o.x - f.p0.x) + fabsf(o.y - f.p0.y) + fabsf(o.z - f.p0.z);
+            const bool behind = dist < -1e-4f * sc;
+            const bool infront = dot(on, f.p0 - o) > 1e-4f * sc && dot(on, f.p1 - o) > 1e-4f * sc &&
+                                 dot(on, f.p2 - o) > 1e-4f * sc;
+            dark = behind && infront;
+        }
+        if (dark) {
+            if (visp)
+                for (int wi = 0; wi < a.vis_words; ++wi) visp[(size_t)wi * F] = 0u;
+            continue;
+        }
+        const Tri tr = load_tri(a.sc.tris, j);
+        const uint64_t kbase = (lg * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
+        uint32_t word = 0;
+        double inten = 0.0;
         for (int s = 0; s < spt; ++s) {
-            Geo g;
+            Geo gg;
             float t_self;
             bool ok = sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, lb, ub, a.sc.vertex_normal,
-                                       a.sc.albedo, g, t_self);
+                                       a.sc.albedo, gg, t_self);
             float val = 0.0f;
             if (ok) {
-                float ff = -dot(g.n, g.dir) * dot(on, g.dir) / g.h / g.h;
+                float ff = -dot(gg.n, gg.dir) * dot(on, gg.dir) / gg.h / gg.h;
                 if (a.sp.clamp) {
                     ff = emax0(ff);
-                    ok = ff > 0.0f;      // zero contribution in both passes: never trace
+                    ok = ff > 0.0f;
                 }
-                val = f.area * g.alb * ff * ff;
-                if (FEAT & FEAT_GGX) val = val * ggx_eval(a.sp.ggx_alpha, dot(g.n, -g.dir));
+                val = f.area * gg.alb * ff * ff;
+                if (FEAT & FEAT_GGX) val = val * ggx_eval(a.sp.ggx_alpha, dot(gg.n, -gg.dir));
             }
-            if (ok) ok = !occluded(a.sc.nodes, a.sc.n_nodes, a.sc.tris, a.sc.face_id, o, g.dir, t_self, j, f.fid);
+            if (ok) {
+                if (use_grid && gg.dir.z > 0.0f) {
+                    const float iz = 1.0f / gg.dir.z;
+                    const int cxx = cell_coord(gg.dir.x * iz, g.gx0, g.inv_cw, R);
+                    const int cyy = cell_coord(gg.dir.y * iz, g.gy0, g.inv_ch, R);
+                    const int c = cyy * R + cxx;
+                    const uint32_t e1 = s_cell[c];
+                    uint32_t e = c > 0 ? s_cell[c - 1] : 0u;
+                    const float zs = t_self * gg.dir.z;                 // depth of the own-face hit
+                    const float zlim = zs + 1e-5f * zs;
+                    for (; e < e1; ++e) {
+                        const int k = (int)s_ent[e];
+                        if (k == j) continue;
+                        const Tri tk = load_tri(a.sc.tris, k);
+                        // entirely deeper than the own hit -> cannot be in front of it
+                        const float zmin = fminf(fminf(tk.p0.z, tk.p0.z - tk.e1.z), tk.p0.z + tk.e2.z) - o.z;
+                        if (zmin > zlim + 1e-6f * fabsf(tk.p0.z)) continue;
+                        float t, u, v;
+                        if (tri_test(tk, o, gg.dir, t, u, v)) {
+                            if (t < t_self || (t == t_self && a.sc.face_id[k] < f.fid)) { ok = false; break; }
+                        }
+                    }
+                } else {
+                    ok = !occluded(a.sc.nodes, a.sc.n_nodes, a.sc.tris, a.sc.face_id, o, gg.dir, t_self, j, f.fid);
+                }
+            }
             if (ok) {
                 word |= 1u << (s & 31);
                 if (a.mode_intensity) {
                     inten += (double)val / (double)spt;
                 } else {
-                    int bin = (int)floorf((2.0f * g.h - lb) / res);
+                    int bin = (int)floorf((2.0f * gg.h - lb) / res);
                     if (bin >= 0 && bin < nbins) {
-                        double c = (double)val / (double)spt;
-                        if (rows_in_lds) unsafeAtomicAdd(&s_row[bin], c);
-                        else unsafeAtomicAdd(&grow[bin], c);
+                        double cc = (double)val / (double)spt;
+                        if (rows_in_lds) unsafeAtomicAdd(&s_row[bin], cc);
+                        else unsafeAtomicAdd(&grow[bin], cc);
                     }
                 }
             }
@@ -194,7 +542,7 @@ __global__ __launch_bounds__(256) void k_forward(ForwardArgs a, int rows_in_lds)
     }
     if (rows_in_lds && grow) {
         __syncthreads();
-        for (int i = threadIdx.x; i < nbins; i += blockDim.x) grow[i] = s_row[i];
+        for (int i = tid; i < nbins; i += NT) grow[i] = s_row[i];
     }
 }
 
@@ -321,13 +669,61 @@ __device__ __forceinline__ int tap_bin(double twoh, double delta, double lb, dou
     return (int)fl;
 }
 
-template <int FEAT>
+// Grouped taps (mode 0).  bin_i is non-decreasing in i and takes at most 4*sigma_bin+2 distinct
+// values, so sum_i w_i d[bin_i] = sum_b d[b] * (P0[end_b] - P0[start_b]) with host-side prefix sums
+// P0 = cumsum(float(w)), P1 = cumsum(g * float(w)).  The boundary tap of every bin is located from
+// the closed form and then verified with the exact per-tap bin formula, so tap->bin assignment is
+// identical to the reference's literal loop.
+struct TapTables {
+    const double* delta;   // [K]
+    const double* p0;      // [K+1]
+    const double* p1;      // [K+1]
+    int K, two_rs;
+    double r_over_res;     // refine / res
+};
+
+__device__ __forceinline__ void grouped_taps(const TapTables& tt, const double* __restrict__ s_diff, int T,
+                                             double twoh, double lbd, double resd, double inv_res,
+                                             double& s0, double& s1) {
+    s0 = 0.0;
+    s1 = 0.0;
+    const int K = tt.K;
+    const int b_first = tap_bin(twoh, tt.delta[0], lbd, resd, inv_res);
+    const int b_last = tap_bin(twoh, tt.delta[K - 1], lbd, resd, inv_res);
+    int i_start = 0;
+    for (int b = b_first; b <= b_last; ++b) {
+        int ie = K;
+        if (b < b_last) {
+            // first tap whose bin exceeds b: delta_i >= (b+1)*res + lb - 2h
+            double thr = ((double)(b + 1) * resd + lbd) - twoh;
+            int ic = (int)ceil(thr * tt.r_over_res) + tt.two_rs;
+            ic = max(i_start, min(K, ic));
+            while (ic > i_start && tap_bin(twoh, tt.delta[ic - 1], lbd, resd, inv_res) > b) --ic;
+            while (ic < K && tap_bin(twoh, tt.delta[ic], lbd, resd, inv_res) <= b) ++ic;
+            ie = ic;
+        }
+        if (b >= 0 && b < T && ie > i_start) {
+            double dd = (double)(float)((-2) * s_diff[b]);
+            s0 += dd * (tt.p0[ie] - tt.p0[i_start]);
+            s1 += dd * (tt.p1[ie] - tt.p1[i_start]);
+        }
+        i_start = ie;
+    }
+}
+
+// MODE 0: per-vertex gradient [V,3]; 1: scalar d/d albedo; 2: scalar d/d alpha (GGX);
+//      3: single-vertex per-bin gradient [T,3]
+template <int FEAT, int MODE>
 __global__ __launch_bounds__(512) void k_gradient(GradientArgs a) {
-    extern __shared__ double s_mem[];       // [ticket (8 B)][diff row T][grad 3V]
+    extern __shared__ double s_mem[];       // [ticket (8 B)][diff row T][tap tables 3K+2][grad 3V]
     int* s_next = reinterpret_cast<int*>(s_mem);
     const int T = a.sp.nbins;
+    const int K = a.K;
     double* s_diff = s_mem + 1;             // [T]
-    double* s_grad = s_mem + 1 + T;         // [3V] when lds_grad
+    double* s_delta = s_diff + T;           // [K]
+    double* s_p0 = s_delta + K;             // [K+1]
+    double* s_p1 = s_p0 + K + 1;            // [K+1]
+    double* s_grad = s_p1 + K + 1;          // [3V] when lds_grad
     const int F = a.sc.F, V = a.sc.V;
     const int spt = a.sp.spt;
     const int lane = threadIdx.x & 63;
@@ -335,9 +731,13 @@ __global__ __launch_bounds__(512) void k_gradient(GradientArgs a) {
     const int Ltot = a.src.total_sources > 0 ? a.src.total_sources : a.src.L;
     const double lbd = (double)a.sp.lb, resd = (double)a.sp.res, inv_res = 1.0 / resd;
 
-    if (a.mode == 0 && a.lds_grad)
+    for (int i = threadIdx.x; i < K; i += blockDim.x) s_delta[i] = a.tap_delta[i];
+    for (int i = threadIdx.x; i <= K; i += blockDim.x) { s_p0[i] = a.tap_p0[i]; s_p1[i] = a.tap_p1[i]; }
+    if (MODE == 0 && a.lds_grad)
         for (int i = threadIdx.x; i < 3 * V; i += blockDim.x) s_grad[i] = 0.0;
     double scalar_acc = 0.0;
+    TapTables tt;
+    tt.delta = s_delta; tt.p0 = s_p0; tt.p1 = s_p1; tt.K = K; tt.two_rs = a.two_rs; tt.r_over_res = a.r_over_res;
 
     for (int l = blockIdx.x; l < a.src.L; l += gridDim.x) {
         __syncthreads();                    // previous source done with s_diff
@@ -358,10 +758,9 @@ __global__ __launch_bounds__(512) void k_gradient(GradientArgs a) {
             for (int wi = 0; wi < a.vis_words; ++wi) any |= visp[(size_t)wi * F];
             if (!any) continue;
             const Face f = load_face(a.sc.facerec, j);
-            if (a.mode == 3 && f.i0 != a.vertex_num && f.i1 != a.vertex_num && f.i2 != a.vertex_num) continue;
+            if (MODE == 3 && f.i0 != a.vertex_num && f.i1 != a.vertex_num && f.i2 != a.vertex_num) continue;
             const Tri tr = load_tri(a.sc.tris, j);
             const uint64_t kbase = (lg * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
-            const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
             double acc[9];
 #pragma unroll
             for (int q = 0; q < 9; ++q) acc[q] = 0.0;
@@ -379,19 +778,19 @@ __global__ __launch_bounds__(512) void k_gradient(GradientArgs a) {
                                           a.sc.vertex_normal, a.sc.albedo, g, t_self))
                         continue;   // cannot happen: pass 1 accepted this sample with the same arithmetic
                     const double twoh = (double)(2.0f * g.h);
-                    if (a.mode == 1 || a.mode == 2) {
-                        // rows A / GGX alpha: scalar gradients
+                    if (MODE == 1 || MODE == 2) {
+                        // rows A / GGX alpha: scalar gradients (literal tap loop, double weights)
                         float c2 = dot(on, g.dir);
                         float c3 = dot(g.n, -g.dir);
                         if (c2 < 0) c2 = 0;
                         if (c3 < 0) c3 = 0;
                         float ff = c2 * c3 / g.h / g.h;
                         double g0;
-                        if (a.mode == 2) g0 = (double)(g.alb * ff * ff * ggx_eval_adiff(a.sp.ggx_alpha, dot(g.n, -g.dir)));
+                        if (MODE == 2) g0 = (double)(g.alb * ff * ff * ggx_eval_adiff(a.sp.ggx_alpha, dot(g.n, -g.dir)));
                         else g0 = (double)(ff * ff);
                         double s0 = 0.0;
-                        for (int i = 0; i < a.K; ++i) {
-                            int bin = tap_bin(twoh, a.tap_delta[i], lbd, resd, inv_res);
+                        for (int i = 0; i < K; ++i) {
+                            int bin = tap_bin(twoh, s_delta[i], lbd, resd, inv_res);
                             if (bin >= 0 && bin < T) s0 += a.tap_w[i] * (-2) * s_diff[bin];
                         }
                         sacc += (double)f.area * g0 * s0 / (double)spt;
@@ -399,15 +798,16 @@ __global__ __launch_bounds__(512) void k_gradient(GradientArgs a) {
                     }
                     GVec gv;
                     grad_vectors<FEAT>(f, g, on, a.normal_term, a.v1_style, a.sp.ggx_alpha, gv);
+                    const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
                     const V3 ce0 = cross(gv.t2, e0), ce1 = cross(gv.t2, e1), ce2 = cross(gv.t2, e2);
-                    if (a.mode == 3) {
+                    if (MODE == 3) {
                         // single-vertex per-bin gradient: output indexed by the tap's bin
                         V3 ce; float bw;
                         if (a.vertex_num == f.i0) { ce = ce0; bw = g.u; }
                         else if (a.vertex_num == f.i1) { ce = ce1; bw = g.v; }
                         else { ce = ce2; bw = g.w; }
-                        for (int i = 0; i < a.K; ++i) {
-                            int bin = tap_bin(twoh, a.tap_delta[i], lbd, resd, inv_res);
+                        for (int i = 0; i < K; ++i) {
+                            int bin = tap_bin(twoh, s_delta[i], lbd, resd, inv_res);
                             if (bin < 0 || bin >= T) continue;
                             V3 gg = g.dir * (float)a.tap_g[i];
                             V3 q = ((gv.t1 + gg * gv.inten_f) * bw + ce) * (float)a.tap_w[i];
@@ -418,18 +818,10 @@ __global__ __launch_bounds__(512) void k_gradient(GradientArgs a) {
                         }
                         continue;
                     }
-                    // mode 0: the K-tap loop factors into two scalar sums per sample:
+                    // MODE 0: the K-tap loop factors into two scalar sums per sample:
                     //   sum_i (t1*b + t2 x e) w_i d_i  +  b * I * dir * sum_i g_i w_i d_i
-                    double s0 = 0.0, s1 = 0.0;
-                    for (int i = 0; i < a.K; ++i) {
-                        int bin = tap_bin(twoh, a.tap_delta[i], lbd, resd, inv_res);
-                        if (bin >= 0 && bin < T) {
-                            float dd = (float)((-2) * s_diff[bin]);
-                            double wd = (double)((float)a.tap_w[i] * dd);
-                            s0 += wd;
-                            s1 += a.tap_g[i] * wd;
-                        }
-                    }
+                    double s0, s1;
+                    grouped_taps(tt, s_diff, T, twoh, lbd, resd, inv_res, s0, s1);
                     const V3 di = g.dir * gv.inten_f;
                     const float bw[3] = {g.u, g.v, g.w};
                     const V3 ce[3] = {ce0, ce1, ce2};
@@ -443,7 +835,7 @@ __global__ __launch_bounds__(512) void k_gradient(GradientArgs a) {
                     }
                 }
             }
-            if (a.mode == 0) {
+            if (MODE == 0) {
                 const double sc = (double)f.area / (double)spt;
                 const int vi[3] = {f.i0, f.i1, f.i2};
 #pragma unroll
@@ -455,20 +847,20 @@ __global__ __launch_bounds__(512) void k_gradient(GradientArgs a) {
                         else unsafeAtomicAdd(&a.out[3 * (size_t)vi[q] + c], val / (double)Ltot);
                     }
                 }
-            } else if (a.mode == 1 || a.mode == 2) {
+            } else if (MODE == 1 || MODE == 2) {
                 scalar_acc += sacc;
             }
         }
     }
     __syncthreads();
-    if (a.mode == 0 && a.lds_grad) {
+    if (MODE == 0 && a.lds_grad) {
         const double invL = 1.0 / (double)Ltot;
         for (int i = threadIdx.x; i < 3 * V; i += blockDim.x) {
             double v = s_grad[i];
             if (v != 0.0) unsafeAtomicAdd(&a.out[i], v * invL);
         }
     }
-    if (a.mode == 1 || a.mode == 2) {
+    if (MODE == 1 || MODE == 2) {
         for (int off = 32; off > 0; off >>= 1) scalar_acc += __shfl_down(scalar_acc, off);
         if (lane == 0 && scalar_acc != 0.0) unsafeAtomicAdd(&a.out[0], scalar_acc / (double)Ltot);
     }
@@ -512,16 +904,51 @@ __global__ __launch_bounds__(256) void k_zero_f64(double* p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0.0;
 }
 
+// LDS budget of the grid kernel: two 512-thread workgroups per CU (160 KiB / 2, minus slack)
+constexpr size_t kGridLdsBudget = 78 * 1024;
+
+template <int FEAT>
+bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
+    if (a.force_bvh || a.sc.F > 65535 || a.sc.F < 64) return false;
+    int R = (int)lrintf(sqrtf(0.5f * (float)a.sc.F));
+    R = std::min(std::max(R, 8), 96);
+    const size_t fixed = 16 + (rows_in_lds ? (size_t)a.sp.nbins * sizeof(double) : 0) + ((size_t)R * R + 1) * 4;
+    if (fixed + 2 * 3 * (size_t)a.sc.F > kGridLdsBudget) return false;      // want room for >= 3 entries per face
+    size_t cap = (kGridLdsBudget - fixed) / 2;
+    if (cap > 65535) cap = 65535;
+    const size_t lds = fixed + cap * 2;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT>), dim3(a.src.L), dim3(512), lds, stream, a, rows_in_lds, R,
+                       (int)cap);
+    return true;
+}
+
 template <int FEAT>
 void forward_launch(const ForwardArgs& a, int rows_in_lds, size_t lds, hipStream_t stream) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward<FEAT>), dim3(a.src.L), dim3(256), lds, stream, a, rows_in_lds);
+    if (forward_grid_launch<FEAT>(a, rows_in_lds, stream)) return;
+    // chunk = rays traced together per (source, face): 4 when spt <= 4, else 8
+    if (a.sp.spt <= 4)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward<FEAT, 4>), dim3(a.src.L), dim3(256), lds, stream, a, rows_in_lds);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward<FEAT, 8>), dim3(a.src.L), dim3(256), lds, stream, a, rows_in_lds);
+}
+
+template <int FEAT, int MODE>
+void gradient_launch2(const GradientArgs& a, int grid, size_t lds, hipStream_t stream) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, MODE>), dim3(grid), dim3(512), lds, stream, a);
 }
 
 template <int FEAT>
 void gradient_launch(const GradientArgs& a, int grid, size_t lds, hipStream_t stream) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT>), dim3(grid), dim3(512), lds, stream, a);
+    switch (a.mode) {
+        case 0: gradient_launch2<FEAT, 0>(a, grid, lds, stream); break;
+        case 1: gradient_launch2<FEAT, 1>(a, grid, lds, stream); break;
+        case 2: gradient_launch2<FEAT, 2>(a, grid, lds, stream); break;
+        default: gradient_launch2<FEAT, 3>(a, grid, lds, stream); break;
+    }
 }
 
 int feat_of(const SceneView& sc, const SampleParams& sp) {
@@ -566,7 +993,7 @@ void launch_residual(const ResidualArgs& a, hipStream_t stream) {
 
 void launch_gradient(const GradientArgs& a, hipStream_t stream) {
     if (a.src.L <= 0) return;
-    size_t lds = 8 + (size_t)a.sp.nbins * sizeof(double);
+    size_t lds = 8 + ((size_t)a.sp.nbins + 3 * (size_t)a.K + 2) * sizeof(double);
     if (a.mode == 0 && a.lds_grad) lds += 3 * (size_t)a.sc.V * sizeof(double);
     // persistent workgroups: as many as can be co-resident (512 threads each)
     int per_cu = (int)(160 * 1024 / (lds + 64));
