@@ -210,6 +210,7 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a) {
         a.facerec[4 * j + 2] = make_float4(p2.z, __int_as_float(f), __int_as_float(i0), __int_as_float(i1));
         a.facerec[4 * j + 3] = make_float4(__int_as_float(i2), 0.0f, 0.0f, 0.0f);
         a.face_id[j] = f;
+        a.tri_zmin[j] = fminf(fminf(p0.z, p1.z), p2.z);
         float* b = a.box + 6 * (size_t)(n_int + j);
         b[0] = fminf(fminf(p0.x, p1.x), p2.x) - pad;
         b[1] = fminf(fminf(p0.y, p1.y), p2.y) - pad;

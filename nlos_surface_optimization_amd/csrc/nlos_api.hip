@@ -76,7 +76,7 @@ struct nlos_ctx {
     int device = 0;
     // BVH scratch + outputs
     DevBuf keys0, keys1, idx0, idx1, child, range, parent, arrive, box, status;
-    DevBuf nodes, tris, facerec, face_id;
+    DevBuf nodes, tris, facerec, face_id, tri_zmin;
     int built_F = -1, built_V = -1;
     // render scratch
     DevBuf vis, diff, fine, taps, rows_tmp, grad_tmp;
@@ -191,6 +191,7 @@ int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bo
     rc |= c->tris.ensure(sizeof(float4) * 3 * (size_t)nF);
     rc |= c->facerec.ensure(sizeof(float4) * 4 * (size_t)nF);
     rc |= c->face_id.ensure(sizeof(int) * (size_t)nF);
+    rc |= c->tri_zmin.ensure(sizeof(float) * (size_t)nF);
     if (rc) return NLOS_ERR_HIP;
     HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int) * 4, st));
     nlos::BuildArgs b;
@@ -201,6 +202,7 @@ int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bo
     b.arrive = c->arrive.as<int>(); b.box = c->box.as<float>(); b.status = c->status.as<int>();
     b.nodes = c->nodes.as<float4>(); b.tris = c->tris.as<float4>(); b.facerec = c->facerec.as<float4>();
     b.face_id = c->face_id.as<int>();
+    b.tri_zmin = c->tri_zmin.as<float>();
     nlos::launch_build_bvh(b, st);
     HIP_TRY(hipGetLastError());
     c->built_F = nF; c->built_V = nV;
@@ -211,6 +213,7 @@ nlos::SceneView scene_view(const nlos_ctx* c, int nF, int nV, const float* vn, c
     nlos::SceneView s;
     s.nodes = c->nodes.as<float4>(); s.tris = c->tris.as<float4>(); s.facerec = c->facerec.as<float4>();
     s.face_id = c->face_id.as<int>();
+    s.tri_zmin = c->tri_zmin.as<float>();
     s.n_nodes = 2 * nF - 1; s.F = nF; s.V = nV;
     s.vertex_normal = vn; s.albedo = alb;
     return s;
@@ -266,7 +269,7 @@ void nlos_ctx_destroy(nlos_ctx* c) {
     if (!c) return;
     DeviceGuard g(c->device);
     DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
-                     &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->vis, &c->diff,
+                     &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
                      &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp};
     for (DevBuf* b : all) b->release();
     for (DevBuf& b : c->io) b.release();
@@ -277,7 +280,7 @@ void nlos_ctx_destroy(nlos_ctx* c) {
 int64_t nlos_ctx_scratch_bytes(const nlos_ctx* c) {
     if (!c) return 0;
     const DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
-                           &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->vis, &c->diff,
+                           &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
                            &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp};
     int64_t s = 0;
     for (const DevBuf* b : all) s += (int64_t)b->cap;

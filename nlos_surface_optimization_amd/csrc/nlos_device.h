@@ -97,6 +97,21 @@ __device__ __forceinline__ bool tri_test(const Tri& tr, V3 o, V3 d, float& t, fl
     return true;
 }
 
+// Same arithmetic as tri_test(), straight-line (no early-outs), distance only: used in the
+// candidate loops, where a predicated test is cheaper than divergent branches.
+__device__ __forceinline__ bool tri_hit_t(const Tri& tr, V3 o, V3 d, float& t) {
+    V3 c = tr.p0 - o;
+    V3 r = cross(c, d);
+    float den = dot(tr.ng, d);
+    float aden = fabsf(den);
+    bool sg = (__float_as_uint(den) >> 31) != 0u;
+    float U = flipsign(dot(r, tr.e2), sg);
+    float Vv = flipsign(dot(r, tr.e1), sg);
+    float Tn = flipsign(dot(tr.ng, c), sg);
+    t = Tn * (1.0f / aden);
+    return (den != 0.0f) & (U >= 0.0f) & (Vv >= 0.0f) & (U + Vv <= aden) & (0.0f < Tn);
+}
+
 // -------------------------------------------------------------- BVH node (32 B)
 // Nodes are stored in DFS pre-order.  a = (lo.x, lo.y, lo.z, hi.x),
 // b = (hi.y, hi.z, escape, tri): on a box hit an inner node continues at i+1,

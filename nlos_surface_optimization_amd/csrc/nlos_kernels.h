@@ -24,6 +24,7 @@ struct BuildArgs {
     float4* tris;            // [3*F]       48 B per triangle, Morton order
     float4* facerec;         // [4*F]       64 B per face, Morton order
     int* face_id;            // [F]         original face index of sorted slot j
+    float* tri_zmin;         // [F]         smallest vertex z of sorted triangle j
 };
 void launch_build_bvh(const BuildArgs& a, hipStream_t stream);
 
@@ -33,6 +34,7 @@ struct SceneView {
     const float4* tris;
     const float4* facerec;
     const int* face_id;
+    const float* tri_zmin;
     int n_nodes, F, V;
     const float* vertex_normal;   // [V,3] or null
     const float* albedo;          // [V]   or null

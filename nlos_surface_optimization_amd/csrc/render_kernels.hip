@@ -365,19 +365,25 @@ __device__ __forceinline__ void raster_tri(const GridView& g, V3 o, V3 p0, V3 p1
 
 template <int FEAT>
 __global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in_lds, int R, int cap) {
-    // dynamic LDS: [ctl: ticket, bad, total, pad (16 B)][row nbins f64][cells R*R+1 u32][entries cap u16]
+    // dynamic LDS: [ctl: ticket, bad, total, n_live (16 B)][row nbins f64][cells R*R+1 u32]
+    //              [block masks nblk u64][block bases nblk+1 u32][live F u16][entries cap u16]
     extern __shared__ double s_lds[];
     int* s_ctl = reinterpret_cast<int*>(s_lds);
     double* s_row = s_lds + 2;
     const int nbins = a.sp.nbins;
     const int ncell = R * R;
+    const int F = a.sc.F;
+    const int nblocks = (F + 63) >> 6;
     uint32_t* s_cell = reinterpret_cast<uint32_t*>(s_row + (rows_in_lds ? nbins : 0));
-    uint16_t* s_ent = reinterpret_cast<uint16_t*>(s_cell + ncell + 1);
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(s_cell + ((ncell + 2) & ~1));
+    uint32_t* s_base = reinterpret_cast<uint32_t*>(s_mask + nblocks);
+    uint16_t* s_live = reinterpret_cast<uint16_t*>(s_base + ((nblocks + 2) & ~1));
+    uint16_t* s_ent = s_live + ((F + 3) & ~3);
     __shared__ uint32_t s_scan[512];
 
     const int l = blockIdx.x;
-    const int F = a.sc.F;
     const int tid = threadIdx.x, NT = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = NT >> 6;
     const V3 o = ld3(a.src.origin + 3 * (size_t)l);
     const V3 on = ld3(a.src.normal + 3 * (size_t)l);
 
@@ -403,8 +409,36 @@ __global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in
     if (rows_in_lds)
         for (int i = tid; i < nbins; i += NT) s_row[i] = 0.0;
     for (int i = tid; i <= ncell; i += NT) s_cell[i] = 0u;
-    if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = frame_ok ? 0 : 1; s_ctl[2] = 0; }
+    if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = frame_ok ? 0 : 1; s_ctl[2] = 0; s_ctl[3] = 0; }
     __syncthreads();
+
+    // ---- which faces can contribute at all?  (order-preserving compaction, per 64-face block) ----
+    // With face normals and the clamped form factor, -dot(n,dir) has the sign of dist(o, plane(f))
+    // for every sample of f: if the wall point is clearly behind the face (and the face in front
+    // of the wall), every contribution is exactly 0 -- nothing to sample, nothing to trace.
+    for (int b = wave; b < nblocks; b += nwaves) {
+        const int j = (b << 6) + lane;
+        bool live = false;
+        if (j < F) {
+            const Face f = load_face(a.sc.facerec, j);
+            bool dark = f.degenerate;
+            if (!dark && !(FEAT & FEAT_VN) && a.sp.clamp) {
+                const float dist = dot(f.fn, o - f.p0);
+                const float sc = fabsf(o.x - f.p0.x) + fabsf(o.y - f.p0.y) + fabsf(o.z - f.p0.z);
+                const bool behind = dist < -1e-4f * sc;
+                const bool infront = dot(on, f.p0 - o) > 1e-4f * sc && dot(on, f.p1 - o) > 1e-4f * sc &&
+                                     dot(on, f.p2 - o) > 1e-4f * sc;
+                dark = behind && infront;
+            }
+            live = !dark;
+            if (dark && a.vis) {
+                uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
+                for (int wi = 0; wi < a.vis_words; ++wi) visp[(size_t)wi * F] = 0u;
+            }
+        }
+        const unsigned long long m = __ballot(live);
+        if (lane == 0) s_mask[b] = m;
+    }
 
     if (frame_ok) {
         // ---- counting pass ---------------------------------------------------------------------
@@ -413,7 +447,15 @@ __global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in
             raster_tri(g, o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x),
                        [&](int c) { atomicAdd(&s_cell[c], 1u); });
         }
-        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < nblocks; ++b) { s_base[b] = run; run += (uint32_t)__popcll(s_mask[b]); }
+        s_base[nblocks] = run;
+        s_ctl[3] = (int)run;
+    }
+    if (frame_ok) {
         // ---- exclusive scan of the cell counts (each thread owns a contiguous slice) -------------
         const int per = (ncell + NT - 1) / NT;
         const int c0 = min(tid * per, ncell), c1 = min(c0 + per, ncell);
@@ -430,51 +472,40 @@ __global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in
         uint32_t run = s_scan[tid] - sum;
         for (int c = c0; c < c1; ++c) { uint32_t n = s_cell[c]; s_cell[c] = run; run += n; }
         if (tid == NT - 1) { s_ctl[2] = (int)s_scan[tid]; if ((int)s_scan[tid] > cap) s_ctl[1] = 1; }
-        __syncthreads();
-        // ---- fill pass: s_cell[c] is the write cursor, afterwards the END of cell c ----------------
-        if (s_ctl[1] == 0) {
-            for (int j = tid; j < F; j += NT) {
-                const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
-                raster_tri(g, o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x),
-                           [&](int c) { uint32_t pos = atomicAdd(&s_cell[c], 1u); s_ent[pos] = (uint16_t)j; });
-            }
-        }
-        __syncthreads();
     }
+    __syncthreads();
+    // ---- live list + fill pass: s_cell[c] is the write cursor, afterwards the END of cell c --------
+    for (int b = wave; b < nblocks; b += nwaves) {
+        const unsigned long long m = s_mask[b];
+        if ((m >> lane) & 1ull)
+            s_live[s_base[b] + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((b << 6) + lane);
+    }
+    if (frame_ok && s_ctl[1] == 0) {
+        for (int j = tid; j < F; j += NT) {
+            const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
+            raster_tri(g, o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x),
+                       [&](int c) { uint32_t pos = atomicAdd(&s_cell[c], 1u); s_ent[pos] = (uint16_t)j; });
+        }
+    }
+    __syncthreads();
     const bool use_grid = s_ctl[1] == 0;
+    const int n_live = s_ctl[3];
+    const int live_blocks = (n_live + 63) >> 6;
 
-    // ---- trace + histogram ------------------------------------------------------------------------
+    // ---- trace + histogram: dense lanes over the live faces ----------------------------------------
     const uint64_t lg = (uint64_t)(a.src.source_offset + l);
     const int spt = a.sp.spt;
     const float lb = a.sp.lb, ub = a.sp.ub, res = a.sp.res;
     double* grow = a.rows ? a.rows + (size_t)l * nbins : nullptr;
-    const int nblocks = (F + 63) >> 6;
-    const int lane = tid & 63;
 
     for (;;) {
         const int b = wave_ticket(&s_ctl[0]);
-        if (b >= nblocks) break;
-        const int j = (b << 6) + lane;
-        if (j >= F) continue;
+        if (b >= live_blocks) break;
+        const int li = (b << 6) + lane;
+        if (li >= n_live) continue;
+        const int j = (int)s_live[li];
         const Face f = load_face(a.sc.facerec, j);
         uint32_t* visp = a.vis ? a.vis + ((size_t)l * a.vis_words) * F + j : nullptr;
-        bool dark = f.degenerate;
-        if (!dark && !(FEAT & FEAT_VN) && a.sp.clamp) {
-            // face-normal form factor: -dot(n,dir) has the sign of dist(o, plane(f)) for every sample of
-            // the face; if the wall point is clearly behind the face and the face is in front of the wall,
-            // every clamped form factor is exactly 0 -> nothing to sample, nothing to trace.
-            const float dist = dot(f.fn, o - f.p0);
-            const float sc = fabsf(o.x - f.p0.x) + fabsf(o.y - f.p0.y) + fabsf(o.z - f.p0.z);
-            const bool behind = dist < -1e-4f * sc;
-            const bool infront = dot(on, f.p0 - o) > 1e-4f * sc && dot(on, f.p1 - o) > 1e-4f * sc &&
-                                 dot(on, f.p2 - o) > 1e-4f * sc;
-            dark = behind && infront;
-        }
-        if (dark) {
-            if (visp)
-                for (int wi = 0; wi < a.vis_words; ++wi) visp[(size_t)wi * F] = 0u;
-            continue;
-        }
         const Tri tr = load_tri(a.sc.tris, j);
         const uint64_t kbase = (lg * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
         uint32_t word = 0;
@@ -502,20 +533,22 @@ __global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in
                     const int c = cyy * R + cxx;
                     const uint32_t e1 = s_cell[c];
                     uint32_t e = c > 0 ? s_cell[c - 1] : 0u;
-                    const float zs = t_self * gg.dir.z;                 // depth of the own-face hit
-                    const float zlim = zs + 1e-5f * zs;
-                    for (; e < e1; ++e) {
+                    // candidates entirely deeper than the own-face hit cannot be in front of it
+                    const float zs = t_self * gg.dir.z;
+                    const float zlim = o.z + zs + 2e-5f * zs;
+                    bool occ = false;
+                    for (; e < e1 && !occ; ++e) {
                         const int k = (int)s_ent[e];
-                        if (k == j) continue;
-                        const Tri tk = load_tri(a.sc.tris, k);
-                        // entirely deeper than the own hit -> cannot be in front of it
-                        const float zmin = fminf(fminf(tk.p0.z, tk.p0.z - tk.e1.z), tk.p0.z + tk.e2.z) - o.z;
-                        if (zmin > zlim + 1e-6f * fabsf(tk.p0.z)) continue;
-                        float t, u, v;
-                        if (tri_test(tk, o, gg.dir, t, u, v)) {
-                            if (t < t_self || (t == t_self && a.sc.face_id[k] < f.fid)) { ok = false; break; }
+                        const float zmin = a.sc.tri_zmin[k];
+                        if (k != j && zmin <= zlim) {
+                            const Tri tk = load_tri(a.sc.tris, k);
+                            float t;
+                            const bool hit = tri_hit_t(tk, o, gg.dir, t);
+                            occ = hit & (t < t_self);
+                            if (hit & (t == t_self)) occ = a.sc.face_id[k] < f.fid;
                         }
                     }
+                    ok = !occ;
                 } else {
                     ok = !occluded(a.sc.nodes, a.sc.n_nodes, a.sc.tris, a.sc.face_id, o, gg.dir, t_self, j, f.fid);
                 }
@@ -912,7 +945,9 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
     if (a.force_bvh || a.sc.F > 65535 || a.sc.F < 64) return false;
     int R = (int)lrintf(sqrtf(0.5f * (float)a.sc.F));
     R = std::min(std::max(R, 8), 96);
-    const size_t fixed = 16 + (rows_in_lds ? (size_t)a.sp.nbins * sizeof(double) : 0) + ((size_t)R * R + 1) * 4;
+    const size_t nblk = ((size_t)a.sc.F + 63) / 64;
+    const size_t fixed = 16 + (rows_in_lds ? (size_t)a.sp.nbins * sizeof(double) : 0) + (((size_t)R * R + 2) & ~(size_t)1) * 4 +
+                         nblk * 8 + ((nblk + 2) & ~(size_t)1) * 4 + (((size_t)a.sc.F + 3) & ~(size_t)3) * 2;
     if (fixed + 2 * 3 * (size_t)a.sc.F > kGridLdsBudget) return false;      // want room for >= 3 entries per face
     size_t cap = (kGridLdsBudget - fixed) / 2;
     if (cap > 65535) cap = 65535;
