@@ -5,13 +5,19 @@
 // rtcNewScene / RTC_BUILD_QUALITY_HIGH / rtcCommitScene every call).  The mesh
 // moves every optimisation step, so the build must be cheap and stay on the
 // device: one 1024-thread workgroup runs all phases back to back
-//   bounds -> 30-bit Morton keys -> LDS-counted radix sort (10 x 3 bit) ->
-//   Karras radix tree -> bottom-up box refit -> DFS pre-order emission
+//   bounds -> 30-bit Morton keys -> LDS-counted radix sort (6 x 5 bit) ->
+//   Karras radix tree + escape links -> bottom-up box refit + node emission
 // with workgroup barriers between phases (no host round trip, one launch,
-// graph-capturable).  Output is a stackless BVH: 32-byte nodes in pre-order with
-// escape indices, 48-byte triangle records and 64-byte face records in Morton
-// order (see nlos_device.h).  Morton order is also the order in which the render
-// kernels hand faces to lanes, so the rays of a wave are spatially coherent.
+// graph-capturable).  Output is a stackless BVH: 32-byte nodes
+//   a = (lo.x, lo.y, lo.z, hi.x), b = (hi.y, hi.z, escape, link)
+// where link >= 0 is the left child of an inner node and link < 0 marks a leaf
+// holding triangle ~link; on a box hit an inner node continues at `link`,
+// otherwise (miss, or leaf) at `escape` (-1 = done).  Node ids: inner i in
+// [0, F-2] (0 = root), leaf j -> F-1+j.  The escape link needs no top-down pass:
+// it is the node whose leaf range starts right after this node's range, i.e.
+// inner node s = last+1 if that node's range starts at s, else leaf s.
+// Triangle (48 B) and face (64 B) records are emitted in Morton order, which is
+// also the order in which the render kernels hand faces to lanes.
 #include "nlos_device.h"
 #include "nlos_kernels.h"
 
@@ -20,9 +26,9 @@ namespace nlos {
 namespace {
 
 constexpr int BT = 1024;          // build threads (one workgroup)
-constexpr int RBITS = 3;          // radix bits per pass
-constexpr int RDIG = 1 << RBITS;  // 8 digits
-constexpr int RPASS = 10;         // 30-bit keys
+constexpr int RBITS = 5;          // radix bits per pass
+constexpr int RDIG = 1 << RBITS;  // 32 digits
+constexpr int RPASS = 6;          // 30-bit keys
 
 __device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
     v = (v * 0x00010001u) & 0xFF0000FFu;
@@ -44,21 +50,37 @@ __device__ __forceinline__ int clamp_index(int v, int nV, int* status) {
     return v;
 }
 
+__device__ __forceinline__ void emit_node(const BuildArgs& a, int id, const float* b, int esc, int link) {
+    a.nodes[2 * id] = make_float4(b[0], b[1], b[2], b[3]);
+    a.nodes[2 * id + 1] = make_float4(b[4], b[5], __int_as_float(esc), __int_as_float(link));
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a) {
-    __shared__ uint32_t s_cnt[RDIG * BT];     // 32 KB radix counters [digit][thread]
-    __shared__ uint32_t s_part[BT];
+    extern __shared__ uint32_t s_dyn[];       // radix counters [RDIG * BT] (128 KB)
+    __shared__ uint32_t s_wsum[BT / 64];
     __shared__ float s_red[6 * 16];           // per-wave bounds
     __shared__ float s_bounds[8];             // lo[3], hi[3], pad
+    uint32_t* s_cnt = s_dyn;
+    // flat index e -> e + e/32: the scan's stride-32 walk (thread t owns [32t, 32t+32)) then
+    // lands on 33-word strides, i.e. distinct LDS banks across a wave
+    auto SK = [](int e) { return e + (e >> 5); };
 
     const int tid = threadIdx.x;
     const int F = a.F;
     const int lane = tid & 63, wave = tid >> 6;
+#ifdef NLOS_BUILD_STAMPS
+    // diagnostic build only: cycles per phase -> status[4..9] (never read by the product path)
+    long long t_prev = clock64();
+    int t_slot = 4;
+#define NLOS_STAMP() do { __syncthreads(); if (tid == 0) { long long t_now = clock64(); a.status[t_slot++] = (int)(t_now - t_prev); t_prev = t_now; } } while (0)
+#else
+#define NLOS_STAMP() do { } while (0)
+#endif
 
-    // ---- phase 1: centroid bounds + scene extent -------------------------------
+    // ---- phase 1: scene bounds --------------------------------------------------
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    float ext = 0.0f;
     for (int f = tid; f < F; f += BT) {
         for (int k = 0; k < 3; ++k) {
             int vi = clamp_index(a.faces[3 * f + k], a.V, a.status);
@@ -66,7 +88,6 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a) {
                 float x = a.vertices[3 * (size_t)vi + c];
                 lo[c] = fminf(lo[c], x);
                 hi[c] = fmaxf(hi[c], x);
-                ext = fmaxf(ext, fabsf(x));
             }
         }
     }
@@ -95,6 +116,7 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a) {
     }
     __syncthreads();
     const float pad = s_bounds[6];
+    NLOS_STAMP();
 
     // ---- phase 2: Morton keys ---------------------------------------------------
     uint32_t* keys_in = a.keys0;
@@ -121,33 +143,35 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a) {
         }
     }
     __syncthreads();
+    NLOS_STAMP();
 
     // ---- phase 3: stable LSD radix sort, one private counter column per thread ----
+    // counters are laid out [digit][thread]; the exclusive scan runs over that flat order
     const int chunk = (F + BT - 1) / BT;
     const int c0 = min(tid * chunk, F), c1 = min(c0 + chunk, F);
     for (int pass = 0; pass < RPASS; ++pass) {
         const int shift = pass * RBITS;
-        for (int d = 0; d < RDIG; ++d) s_cnt[d * BT + tid] = 0;
-        for (int i = c0; i < c1; ++i) s_cnt[((keys_in[i] >> shift) & (RDIG - 1)) * BT + tid] += 1;
+        for (int d = 0; d < RDIG; ++d) s_cnt[SK(d * BT + tid)] = 0;
+        for (int i = c0; i < c1; ++i) s_cnt[SK(((keys_in[i] >> shift) & (RDIG - 1)) * BT + tid)] += 1;
         __syncthreads();
-        // exclusive scan of s_cnt in (digit, thread) order: thread t owns entries [8t, 8t+8)
-        uint32_t loc[RDIG];
+        // thread t owns flat entries [RDIG*t, RDIG*t + RDIG)
         uint32_t sum = 0;
-        for (int q = 0; q < RDIG; ++q) { loc[q] = sum; sum += s_cnt[tid * RDIG + q]; }
-        s_part[tid] = sum;
-        __syncthreads();
-        for (int off = 1; off < BT; off <<= 1) {
-            uint32_t v = tid >= off ? s_part[tid - off] : 0;
-            __syncthreads();
-            s_part[tid] += v;
-            __syncthreads();
+        for (int q = 0; q < RDIG; ++q) sum += s_cnt[SK(tid * RDIG + q)];
+        uint32_t incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
         }
-        uint32_t base = s_part[tid] - sum;
-        for (int q = 0; q < RDIG; ++q) s_cnt[tid * RDIG + q] = base + loc[q];
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += s_wsum[w];
+        uint32_t run = wbase + incl - sum;
+        for (int q = 0; q < RDIG; ++q) { uint32_t n = s_cnt[SK(tid * RDIG + q)]; s_cnt[SK(tid * RDIG + q)] = run; run += n; }
         __syncthreads();
         for (int i = c0; i < c1; ++i) {
             uint32_t k = keys_in[i];
-            uint32_t dst = s_cnt[((k >> shift) & (RDIG - 1)) * BT + tid]++;
+            uint32_t dst = s_cnt[SK(((k >> shift) & (RDIG - 1)) * BT + tid)]++;
             keys_out[dst] = k;
             idx_out[dst] = idx_in[i];
         }
@@ -155,12 +179,11 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a) {
         uint32_t* tk = keys_in; keys_in = keys_out; keys_out = tk;
         int* ti = idx_in; idx_in = idx_out; idx_out = ti;
     }
-    // sorted data is in keys_in / idx_in (RPASS even -> back in keys0 / idx0)
     const uint32_t* keys = keys_in;
     const int* order = idx_in;
+    NLOS_STAMP();
 
     // ---- phase 4: Karras radix tree ------------------------------------------------
-    // temp node ids: internal i -> i (0..F-2), leaf j -> F-1+j
     const int n_int = F - 1;
     for (int i = tid; i < n_int; i += BT) {
         int d = (delta(keys, F, i, i + 1) - delta(keys, F, i, i - 1)) >= 0 ? 1 : -1;
@@ -191,8 +214,17 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a) {
     }
     if (tid == 0) a.parent[F > 1 ? 0 : n_int] = -1;
     __syncthreads();
+    NLOS_STAMP();
 
-    // ---- phase 5: leaf records + bottom-up refit -------------------------------------
+    // escape link of the node covering leaves [first, last]
+    auto escape_of = [&](int last) -> int {
+        const int s = last + 1;
+        if (s >= F) return -1;
+        if (s < n_int && a.range[2 * s] == s) return s;      // inner node s starts at leaf s
+        return n_int + s;                                    // otherwise the leaf itself
+    };
+
+    // ---- phase 5: leaf records + bottom-up refit + node emission -------------------------
     for (int j = tid; j < F; j += BT) {
         int f = order[j];
         int i0 = clamp_index(a.faces[3 * f], a.V, a.status);
@@ -218,51 +250,39 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a) {
         b[3] = fmaxf(fmaxf(p0.x, p1.x), p2.x) + pad;
         b[4] = fmaxf(fmaxf(p0.y, p1.y), p2.y) + pad;
         b[5] = fmaxf(fmaxf(p0.z, p1.z), p2.z) + pad;
-        __threadfence();
+        emit_node(a, n_int + j, b, escape_of(j), ~j);
+        // One workgroup = one CU: a workgroup-scope release (s_waitcnt vmcnt(0): the write-through
+        // stores have reached the L2) orders the box before the arrival count; the second arriver
+        // reads the sibling's box with L1-bypassing loads.  No device-wide cache flushes needed.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         int node = a.parent[n_int + j];
         while (node >= 0) {
             int old = atomicAdd(&a.arrive[node], 1);
             if (old == 0) break;                   // sibling subtree not finished yet
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             const float* bl = a.box + 6 * (size_t)a.child[2 * node];
             const float* br = a.box + 6 * (size_t)a.child[2 * node + 1];
             float* bo = a.box + 6 * (size_t)node;
-            // the sibling's box was written by another wave: read it through the L2
+            float nb[6];
             for (int c = 0; c < 6; ++c) {
                 float x = __hip_atomic_load(bl + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 float y = __hip_atomic_load(br + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bo[c] = c < 3 ? fminf(x, y) : fmaxf(x, y);
+                nb[c] = c < 3 ? fminf(x, y) : fmaxf(x, y);
+                bo[c] = nb[c];
             }
-            __threadfence();
+            emit_node(a, node, nb, escape_of(a.range[2 * node + 1]), a.child[2 * node]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             node = a.parent[node];
         }
     }
-    __syncthreads();
-
-    // ---- phase 6: DFS pre-order emission ---------------------------------------------
-    // pre(node) = 2 * first_leaf(node) + (number of ancestors entered through their LEFT child)
-    const int n_nodes = 2 * F - 1;
-    for (int t = tid; t < n_nodes; t += BT) {
-        bool leaf = t >= n_int;
-        int first = leaf ? (t - n_int) : a.range[2 * t];
-        int nleaves = leaf ? 1 : (a.range[2 * t + 1] - a.range[2 * t] + 1);
-        int lt = 0;
-        int node = t, p = a.parent[t];
-        while (p >= 0) {
-            if (a.child[2 * p] == node) ++lt;
-            node = p;
-            p = a.parent[p];
-        }
-        int pre = 2 * first + lt;
-        int esc = pre + 2 * nleaves - 1;
-        const float* b = a.box + 6 * (size_t)t;
-        a.nodes[2 * pre] = make_float4(b[0], b[1], b[2], b[3]);
-        a.nodes[2 * pre + 1] = make_float4(b[4], b[5], __int_as_float(esc), __int_as_float(leaf ? first : -1));
-    }
+    NLOS_STAMP();
 }
 
 void launch_build_bvh(const BuildArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(k_build_bvh, dim3(1), dim3(BT), 0, stream, a);
+    const size_t lds = ((size_t)RDIG * BT + (size_t)RDIG * BT / 32 + 32) * sizeof(uint32_t);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_bvh), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL(k_build_bvh, dim3(1), dim3(BT), lds, stream, a);
 }
 
 }  // namespace nlos

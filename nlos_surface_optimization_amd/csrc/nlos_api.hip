@@ -186,14 +186,14 @@ int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bo
     rc |= c->parent.ensure(sizeof(int) * n_nodes);
     rc |= c->arrive.ensure(sizeof(int) * (size_t)nF);
     rc |= c->box.ensure(sizeof(float) * 6 * n_nodes);
-    rc |= c->status.ensure(sizeof(int) * 4);
+    rc |= c->status.ensure(sizeof(int) * 16);
     rc |= c->nodes.ensure(sizeof(float4) * 2 * n_nodes);
     rc |= c->tris.ensure(sizeof(float4) * 3 * (size_t)nF);
     rc |= c->facerec.ensure(sizeof(float4) * 4 * (size_t)nF);
     rc |= c->face_id.ensure(sizeof(int) * (size_t)nF);
     rc |= c->tri_zmin.ensure(sizeof(float) * (size_t)nF);
     if (rc) return NLOS_ERR_HIP;
-    HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int) * 4, st));
+    HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int) * 16, st));
     nlos::BuildArgs b;
     b.vertices = V; b.faces = F; b.V = nV; b.F = nF;
     b.keys0 = c->keys0.as<uint32_t>(); b.keys1 = c->keys1.as<uint32_t>();
@@ -205,6 +205,14 @@ int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bo
     b.tri_zmin = c->tri_zmin.as<float>();
     nlos::launch_build_bvh(b, st);
     HIP_TRY(hipGetLastError());
+#ifdef NLOS_BUILD_STAMPS
+    {   // diagnostic builds only: per-phase cycles of the build kernel
+        int h[16];
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(h, c->status.p, sizeof(h), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[build stamps] bounds %d morton %d sort %d karras %d refit %d (cycles)\n", h[4], h[5], h[6], h[7], h[8]);
+    }
+#endif
     c->built_F = nF; c->built_V = nV;
     return NLOS_OK;
 }
@@ -547,8 +555,9 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
                 ga.diff = transient;   // unused by mode 3; any valid [L,T] buffer
                 break;
         }
-        ga.lds_grad = (ga.mode == 0 && (3 * (size_t)nV + (size_t)T + 3 * (size_t)K + 2) * sizeof(double) + 64 <=
-                                           (size_t)nlos::kGradLdsBudget) ? 1 : 0;
+        // LDS: diff row + tap tables + 3V accumulator + live-face list (4.2 B per face)
+        ga.lds_grad = (ga.mode == 0 && (3 * (size_t)nV + (size_t)T + 3 * (size_t)K + 2) * sizeof(double) +
+                                           5 * (size_t)nF + 128 <= (size_t)nlos::kGradLdsBudget) ? 1 : 0;
         nlos::launch_gradient(ga, st);
     }
     mark(c, 4, st);

@@ -113,10 +113,10 @@ __device__ __forceinline__ bool tri_hit_t(const Tri& tr, V3 o, V3 d, float& t) {
 }
 
 // -------------------------------------------------------------- BVH node (32 B)
-// Nodes are stored in DFS pre-order.  a = (lo.x, lo.y, lo.z, hi.x),
-// b = (hi.y, hi.z, escape, tri): on a box hit an inner node continues at i+1,
-// otherwise (miss, or leaf) traversal continues at `escape` -- no stack.
-// tri >= 0 marks a leaf (index into the sorted triangle array).
+// a = (lo.x, lo.y, lo.z, hi.x), b = (hi.y, hi.z, escape, link).  link >= 0: left child of an
+// inner node; link < 0: leaf holding sorted triangle ~link.  On a box hit an inner node
+// continues at `link`, otherwise (miss, or leaf) at `escape` (-1 = done) -- no stack.
+// Node 0 is the root (see bvh_build.hip).
 struct RayBox {
     float ox, oy, oz, ix, iy, iz;
 };
@@ -152,15 +152,15 @@ __device__ __forceinline__ bool occluded(const float4* __restrict__ nodes, int n
     rb.ox = o.x; rb.oy = o.y; rb.oz = o.z;
     rb.ix = safe_inv(d.x); rb.iy = safe_inv(d.y); rb.iz = safe_inv(d.z);
     int i = 0;
-    while (i < n_nodes) {
+    while (i >= 0) {
         int leaf = -1;
-        while (i < n_nodes) {
+        while (i >= 0) {
             float4 a = nodes[2 * i], b = nodes[2 * i + 1];
             bool hit = box_test(a, b, rb, t_self);
             int esc = __float_as_int(b.z);
-            int tri = __float_as_int(b.w);
-            if (hit && tri >= 0) { leaf = tri; i = esc; break; }
-            i = hit ? i + 1 : esc;
+            int link = __float_as_int(b.w);
+            if (hit && link < 0) { leaf = ~link; i = esc; break; }
+            i = hit ? link : esc;
         }
         if (leaf >= 0 && leaf != self) {
             Tri tr = load_tri(tris, leaf);
@@ -184,12 +184,13 @@ __device__ __forceinline__ int closest_hit(const float4* __restrict__ nodes, int
     int best = -1, best_fid = 0x7fffffff;
     bt = __int_as_float(0x7f800000);
     int i = 0;
-    while (i < n_nodes) {
+    while (i >= 0) {
         float4 a = nodes[2 * i], b = nodes[2 * i + 1];
         bool hit = box_test(a, b, rb, bt);
         int esc = __float_as_int(b.z);
-        int tri = __float_as_int(b.w);
-        if (hit && tri >= 0) {
+        int link = __float_as_int(b.w);
+        int tri = ~link;
+        if (hit && link < 0) {
             Tri tr = load_tri(tris, tri);
             float t, u, v;
             if (tri_test(tr, o, d, t, u, v)) {
@@ -199,7 +200,7 @@ __device__ __forceinline__ int closest_hit(const float4* __restrict__ nodes, int
                 }
             }
         }
-        i = (hit && tri < 0) ? i + 1 : esc;
+        i = (hit && link >= 0) ? link : esc;
     }
     return best;
 }

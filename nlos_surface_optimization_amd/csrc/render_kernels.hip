@@ -149,9 +149,9 @@ __device__ __forceinline__ uint32_t trace_packet(const float4* __restrict__ node
     mylo -= 2e-6f * (1.0f + fabsf(mylo)); myhi += 2e-6f * (1.0f + fabsf(myhi));
     zmax += 2e-6f * zmax;
     int i = 0;
-    while (i < n_nodes && alive) {
+    while (i >= 0 && alive) {
         int leaf = -1;
-        while (i < n_nodes) {
+        while (i >= 0) {
             const float4 a = nodes[2 * i], b = nodes[2 * i + 1];
             const float za = fmaxf(a.z - o.z, 0.0f);
             const float zb = fminf(b.y - o.z, zmax);
@@ -160,9 +160,9 @@ __device__ __forceinline__ uint32_t trace_packet(const float4* __restrict__ node
             const bool hit = (za <= zb) && (a.x - o.x <= fxhi) && (a.w - o.x >= fxlo) &&
                              (a.y - o.y <= fyhi) && (b.x - o.y >= fylo);
             const int esc = __float_as_int(b.z);
-            const int tri = __float_as_int(b.w);
-            if (hit && tri >= 0) { leaf = tri; i = esc; break; }
-            i = hit ? i + 1 : esc;
+            const int link = __float_as_int(b.w);
+            if (hit && link < 0) { leaf = ~link; i = esc; break; }
+            i = hit ? link : esc;
         }
         if (leaf >= 0 && leaf != self) {
             const Tri tr = load_tri(tris, leaf);
@@ -748,19 +748,22 @@ __device__ __forceinline__ void grouped_taps(const TapTables& tt, const double* 
 //      3: single-vertex per-bin gradient [T,3]
 template <int FEAT, int MODE>
 __global__ __launch_bounds__(512) void k_gradient(GradientArgs a) {
-    extern __shared__ double s_mem[];       // [ticket (8 B)][diff row T][tap tables 3K+2][grad 3V]
+    extern __shared__ double s_mem[];       // [ticket (8 B)][diff row T][tap tables 3K+2][grad 3V][masks][bases][live]
     int* s_next = reinterpret_cast<int*>(s_mem);
     const int T = a.sp.nbins;
     const int K = a.K;
+    const int F = a.sc.F, V = a.sc.V;
+    const int nblocks = (F + 63) >> 6;
     double* s_diff = s_mem + 1;             // [T]
     double* s_delta = s_diff + T;           // [K]
     double* s_p0 = s_delta + K;             // [K+1]
     double* s_p1 = s_p0 + K + 1;            // [K+1]
     double* s_grad = s_p1 + K + 1;          // [3V] when lds_grad
-    const int F = a.sc.F, V = a.sc.V;
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(s_grad + ((MODE == 0 && a.lds_grad) ? 3 * V : 0));
+    uint32_t* s_base = reinterpret_cast<uint32_t*>(s_mask + nblocks);              // [nblocks+1]
+    uint32_t* s_live = s_base + ((nblocks + 2) & ~1);                               // [F] sorted face slots
     const int spt = a.sp.spt;
-    const int lane = threadIdx.x & 63;
-    const int nblocks = (F + 63) >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int Ltot = a.src.total_sources > 0 ? a.src.total_sources : a.src.L;
     const double lbd = (double)a.sp.lb, resd = (double)a.sp.res, inv_res = 1.0 / resd;
 
@@ -776,20 +779,53 @@ __global__ __launch_bounds__(512) void k_gradient(GradientArgs a) {
         __syncthreads();                    // previous source done with s_diff
         for (int i = threadIdx.x; i < T; i += blockDim.x) s_diff[i] = a.diff[(size_t)l * T + i];
         if (threadIdx.x == 0) *s_next = 0;
+        // faces with at least one accepted sample, compacted in order (pass 1 left the masks)
+        for (int b = wave; b < nblocks; b += nwaves) {
+            const int j = (b << 6) + lane;
+            uint32_t any = 0;
+            if (j < F) {
+                const uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
+                for (int wi = 0; wi < a.vis_words; ++wi) any |= visp[(size_t)wi * F];
+            }
+            const unsigned long long m = __ballot(any != 0u);
+            if (lane == 0) s_mask[b] = m;
+        }
         __syncthreads();
+        if (threadIdx.x < 64) {
+            // wave 0: exclusive scan of the per-block counts
+            uint32_t run = 0;
+            for (int b0 = 0; b0 < nblocks; b0 += 64) {
+                const int b = b0 + lane;
+                uint32_t n = b < nblocks ? (uint32_t)__popcll(s_mask[b]) : 0u;
+                uint32_t incl = n;
+                for (int off = 1; off < 64; off <<= 1) {
+                    uint32_t v = __shfl_up(incl, off);
+                    if (lane >= off) incl += v;
+                }
+                if (b < nblocks) s_base[b] = run + incl - n;
+                run += __shfl(incl, 63);
+            }
+            if (lane == 0) s_base[nblocks] = run;
+        }
+        __syncthreads();
+        for (int b = wave; b < nblocks; b += nwaves) {
+            const unsigned long long m = s_mask[b];
+            if ((m >> lane) & 1ull) s_live[s_base[b] + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)((b << 6) + lane);
+        }
+        __syncthreads();
+        const int n_live = (int)s_base[nblocks];
+        const int live_blocks = (n_live + 63) >> 6;
         const V3 o = ld3(a.src.origin + 3 * (size_t)l);
         const V3 on = ld3(a.src.normal + 3 * (size_t)l);
         const uint64_t lg = (uint64_t)(a.src.source_offset + l);
 
         for (;;) {
             const int b = wave_ticket(s_next);
-            if (b >= nblocks) break;
-            const int j = (b << 6) + lane;
-            if (j >= F) continue;
+            if (b >= live_blocks) break;
+            const int li = (b << 6) + lane;
+            if (li >= n_live) continue;
+            const int j = (int)s_live[li];
             const uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
-            uint32_t any = 0;
-            for (int wi = 0; wi < a.vis_words; ++wi) any |= visp[(size_t)wi * F];
-            if (!any) continue;
             const Face f = load_face(a.sc.facerec, j);
             if (MODE == 3 && f.i0 != a.vertex_num && f.i1 != a.vertex_num && f.i2 != a.vertex_num) continue;
             const Tri tr = load_tri(a.sc.tris, j);
@@ -1030,6 +1066,8 @@ void launch_gradient(const GradientArgs& a, hipStream_t stream) {
     if (a.src.L <= 0) return;
     size_t lds = 8 + ((size_t)a.sp.nbins + 3 * (size_t)a.K + 2) * sizeof(double);
     if (a.mode == 0 && a.lds_grad) lds += 3 * (size_t)a.sc.V * sizeof(double);
+    const size_t nblk = ((size_t)a.sc.F + 63) / 64;
+    lds += nblk * 8 + ((nblk + 2) & ~(size_t)1) * 4 + (size_t)a.sc.F * 4;
     // persistent workgroups: as many as can be co-resident (512 threads each)
     int per_cu = (int)(160 * 1024 / (lds + 64));
     if (per_cu > 4) per_cu = 4;

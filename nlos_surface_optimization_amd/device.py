@@ -92,7 +92,7 @@ class TransientRenderer:
 
     def _args(self, mode, origin, normal, vertices, faces, num_sample, lower_bound, upper_bound,
               resolution, refine_scale=1, sigma_bin=1, vertex_normal=None, albedo=None,
-              source_offset=0, total_sources=0, alpha=None, seed=None):
+              source_offset=0, total_sources=0, alpha=None, seed=None, force_bvh=False):
         a = _lib.RenderArgs()
         self._lib.nlos_render_args_init(ctypes.byref(a))
         _want(origin, torch.float32, "origin", 2); _want(normal, torch.float32, "normal", 2)
@@ -113,6 +113,7 @@ class TransientRenderer:
         a.seed = self.seed if seed is None else int(seed)
         if alpha is not None:
             a.use_ggx, a.ggx_alpha = 1, float(alpha)
+        a.force_bvh = 1 if force_bvh else 0
         return a
 
     def _run(self, a, keep):

@@ -1,0 +1,23 @@
+#!/bin/bash
+# diagnostic: per-phase cycles of k_build_bvh. Builds a stamped copy of the library in /tmp, never the shipped one.
+set -e
+cd "$GRAFT_REPO_ROOT"
+cp -r nlos_surface_optimization_amd /tmp/nlos_stamped && cp -r include /tmp/include
+make -s -C /tmp/nlos_stamped/csrc clean >/dev/null; make -s -C /tmp/nlos_stamped/csrc -j4 EXTRA=-DNLOS_BUILD_STAMPS
+cd /tmp && ln -sf "$GRAFT_REPO_ROOT/tests" tests 2>/dev/null || true
+python3 - <<'PY'
+import sys, importlib.util, numpy as np, torch
+sys.path.insert(0, "/tmp")
+spec = importlib.util.spec_from_file_location("nlos_stamped", "/tmp/nlos_stamped/__init__.py", submodule_search_locations=["/tmp/nlos_stamped"])
+m = importlib.util.module_from_spec(spec); sys.modules["nlos_stamped"] = m; spec.loader.exec_module(m)
+from nlos_stamped import device as nd
+import os
+d = np.load(os.path.join(os.environ["GRAFT_REPO_ROOT"], "tests/golden/bunny_5k.npz"))
+dev = torch.device("cuda", 0)
+r = nd.TransientRenderer(dev)
+v = torch.from_numpy(d["v"]).to(dev); f = torch.from_numpy(d["f"]).to(dev)
+o = torch.zeros((4, 3), device=dev); n = torch.tensor([[0, 0, 1.0]] * 4, device=dev)
+for _ in range(3):
+    r.render_transient(o, n, v, f, 20000, 0.625, 1.625, 2.0 ** -9)
+torch.cuda.synchronize()
+PY
