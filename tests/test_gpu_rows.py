@@ -277,6 +277,7 @@ def test_grid_and_bvh_occlusion_paths_agree_bit_for_bit(bunny, mannequin):
         w = torch.ones_like(tg)
         _, gg, _ = r.render_gradient(to, tn, tv, tf, 20000, lb, ub, res, data=data, weight=w)
         _, gb, _ = r.render_gradient(to, tn, tv, tf, 20000, lb, ub, res, data=data, weight=w, force_bvh=True)
-        # same accepted samples; only the fp64 atomic summation order differs (cancelling terms)
-        assert rel_l2(gg.cpu().numpy(), gb.cpu().numpy()) <= 1e-9
+        # same accepted samples; the transient differs by fp64 add order (1e-16), which the reference's
+        # float conversion of -2*difference (transient_and_gradient.cpp:980) can turn into 1-ulp fp32 flips
+        assert rel_l2(gg.cpu().numpy(), gb.cpu().numpy()) <= 1e-6
     r.close()
