@@ -234,9 +234,10 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a) {
         V3 p1 = ld3(a.vertices + 3 * (size_t)i1);
         V3 p2 = ld3(a.vertices + 3 * (size_t)i2);
         Tri tr = make_tri(p0, p1, p2);
-        a.tris[3 * j] = make_float4(tr.p0.x, tr.p0.y, tr.p0.z, tr.e1.x);
-        a.tris[3 * j + 1] = make_float4(tr.e1.y, tr.e1.z, tr.e2.x, tr.e2.y);
-        a.tris[3 * j + 2] = make_float4(tr.e2.z, tr.ng.x, tr.ng.y, tr.ng.z);
+        a.tris[kTriStride * j] = make_float4(tr.p0.x, tr.p0.y, tr.p0.z, tr.e1.x);
+        a.tris[kTriStride * j + 1] = make_float4(tr.e1.y, tr.e1.z, tr.e2.x, tr.e2.y);
+        a.tris[kTriStride * j + 2] = make_float4(tr.e2.z, tr.ng.x, tr.ng.y, tr.ng.z);
+        a.tris[kTriStride * j + 3] = make_float4(fminf(fminf(p0.z, p1.z), p2.z), __int_as_float(f), 0.0f, 0.0f);
         a.facerec[4 * j] = make_float4(p0.x, p0.y, p0.z, p1.x);
         a.facerec[4 * j + 1] = make_float4(p1.y, p1.z, p2.x, p2.y);
         a.facerec[4 * j + 2] = make_float4(p2.z, __int_as_float(f), __int_as_float(i0), __int_as_float(i1));

@@ -188,7 +188,7 @@ int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bo
     rc |= c->box.ensure(sizeof(float) * 6 * n_nodes);
     rc |= c->status.ensure(sizeof(int) * 16);
     rc |= c->nodes.ensure(sizeof(float4) * 2 * n_nodes);
-    rc |= c->tris.ensure(sizeof(float4) * 3 * (size_t)nF);
+    rc |= c->tris.ensure(sizeof(float4) * 4 * (size_t)nF);
     rc |= c->facerec.ensure(sizeof(float4) * 4 * (size_t)nF);
     rc |= c->face_id.ensure(sizeof(int) * (size_t)nF);
     rc |= c->tri_zmin.ensure(sizeof(float) * (size_t)nF);
@@ -429,6 +429,11 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.vis = nullptr; fa.vis_words = vis_words;
     fa.intensity = a->intensity; fa.mode_intensity = mode == NLOS_MODE_INTENSITY ? 1 : 0;
     fa.force_bvh = a->force_bvh;
+    fa.dbg = nullptr;
+#ifdef NLOS_FWD_STAMPS
+    HIP_TRY(hipMemsetAsync(c->status.p, 0, 16 * sizeof(int), st));
+    fa.dbg = c->status.as<long long>();     // 8 x int64 (diagnostic build only)
+#endif
     fa.rows = nullptr;
     nlos_ctx::VisKey key;
     key.L = L; key.F = nF; key.V = nV; key.spt = spt; key.off = a->source_offset; key.seed = a->seed;
@@ -470,6 +475,15 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         }
     }
     if (!skip_pass1) nlos::launch_forward(fa, st);
+#ifdef NLOS_FWD_STAMPS
+    {
+        long long h[8];
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(h, c->status.p, sizeof(h), hipMemcpyDeviceToHost));
+        double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
+        std::fprintf(stderr, "[fwd stamps] setup %.1f%% count %.1f%% scan %.1f%% fill %.1f%% trace %.1f%% (sum %.3g cycles)\n", 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, tot);
+    }
+#endif
     if (!skip_pass1 && mode != NLOS_MODE_INTENSITY && fwd_refine > 1) {
         // Gaussian of the refined histogram (row FD): kernel = the gradient taps' w
         int K = 0;

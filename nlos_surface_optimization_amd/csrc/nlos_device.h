@@ -52,8 +52,10 @@ __device__ __forceinline__ void sample_st(uint64_t seed, uint64_t k, float& S, f
 }
 
 // ------------------------------------------------------------ triangle record
-// 48-byte record, sorted (Morton) order: p0, e1 = p0-p1, e2 = p2-p0, ng = e2 x e1
+// 64-byte record (one cache-line half, 4 x dwordx4), sorted (Morton) order:
+//   p0, e1 = p0-p1, e2 = p2-p0, ng = e2 x e1, zmin (smallest vertex z), original face id
 struct Tri { V3 p0, e1, e2, ng; };
+constexpr int kTriStride = 4;   // float4 per record
 
 __device__ __forceinline__ Tri make_tri(V3 p0, V3 p1, V3 p2) {
     Tri t;
@@ -65,7 +67,7 @@ __device__ __forceinline__ Tri make_tri(V3 p0, V3 p1, V3 p2) {
 }
 
 __device__ __forceinline__ Tri load_tri(const float4* __restrict__ tris, int j) {
-    float4 a = tris[3 * j], b = tris[3 * j + 1], c = tris[3 * j + 2];
+    float4 a = tris[kTriStride * j], b = tris[kTriStride * j + 1], c = tris[kTriStride * j + 2];
     Tri t;
     t.p0 = mk(a.x, a.y, a.z);
     t.e1 = mk(a.w, b.x, b.y);
@@ -110,6 +112,29 @@ __device__ __forceinline__ bool tri_hit_t(const Tri& tr, V3 o, V3 d, float& t) {
     float Tn = flipsign(dot(tr.ng, c), sg);
     t = Tn * (1.0f / aden);
     return (den != 0.0f) & (U >= 0.0f) & (Vv >= 0.0f) & (U + Vv <= aden) & (0.0f < Tn);
+}
+
+// Occluder test against the own-face hit at distance t_self (original face id self_fid):
+// does triangle `tr` (original id via face_id[k]) give a valid hit that wins the closest-hit rule?
+// Same arithmetic as tri_test(); the division is only reached by lanes with a valid hit (rare).
+__device__ __forceinline__ bool tri_occludes(const Tri& tr, V3 o, V3 d, float t_self, int self_fid,
+                                             const int* __restrict__ face_id, int k) {
+    V3 c = tr.p0 - o;
+    V3 r = cross(c, d);
+    float den = dot(tr.ng, d);
+    float aden = fabsf(den);
+    bool sg = (__float_as_uint(den) >> 31) != 0u;
+    float U = flipsign(dot(r, tr.e2), sg);
+    float Vv = flipsign(dot(r, tr.e1), sg);
+    float Tn = flipsign(dot(tr.ng, c), sg);
+    bool valid = (den != 0.0f) & (U >= 0.0f) & (Vv >= 0.0f) & (U + Vv <= aden) & (0.0f < Tn);
+    bool occ = false;
+    if (valid) {
+        float t = Tn * (1.0f / aden);
+        occ = t < t_self;
+        if (t == t_self) occ = face_id[k] < self_fid;
+    }
+    return occ;
 }
 
 // -------------------------------------------------------------- BVH node (32 B)

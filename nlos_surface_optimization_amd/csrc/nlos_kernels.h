@@ -21,7 +21,7 @@ struct BuildArgs {
     int* status;             // [1] bit0: face index out of range
     // outputs
     float4* nodes;           // [2*(2F-1)]  pre-order, 32 B per node
-    float4* tris;            // [3*F]       48 B per triangle, Morton order
+    float4* tris;            // [4*F]       64 B per triangle, Morton order
     float4* facerec;         // [4*F]       64 B per face, Morton order
     int* face_id;            // [F]         original face index of sorted slot j
     float* tri_zmin;         // [F]         smallest vertex z of sorted triangle j
@@ -69,6 +69,7 @@ struct ForwardArgs {
     double* intensity;       // [F] (mode intensity: accumulated with atomics; rows unused)
     int mode_intensity;
     int force_bvh;           // 1: never use the per-source perspective grid (tests / large meshes)
+    long long* dbg;          // diagnostic builds only (NLOS_FWD_STAMPS); null in the product
 };
 void launch_forward(const ForwardArgs& a, hipStream_t stream);
 

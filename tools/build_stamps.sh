@@ -3,7 +3,7 @@
 set -e
 cd "$GRAFT_REPO_ROOT"
 cp -r nlos_surface_optimization_amd /tmp/nlos_stamped && cp -r include /tmp/include
-make -s -C /tmp/nlos_stamped/csrc clean >/dev/null; make -s -C /tmp/nlos_stamped/csrc -j4 EXTRA=-DNLOS_BUILD_STAMPS
+make -s -C /tmp/nlos_stamped/csrc clean >/dev/null; make -s -C /tmp/nlos_stamped/csrc -j4 EXTRA="-DNLOS_BUILD_STAMPS -DNLOS_FWD_STAMPS"
 cd /tmp && ln -sf "$GRAFT_REPO_ROOT/tests" tests 2>/dev/null || true
 python3 - <<'PY'
 import sys, importlib.util, numpy as np, torch
@@ -16,7 +16,7 @@ d = np.load(os.path.join(os.environ["GRAFT_REPO_ROOT"], "tests/golden/bunny_5k.n
 dev = torch.device("cuda", 0)
 r = nd.TransientRenderer(dev)
 v = torch.from_numpy(d["v"]).to(dev); f = torch.from_numpy(d["f"]).to(dev)
-o = torch.zeros((4, 3), device=dev); n = torch.tensor([[0, 0, 1.0]] * 4, device=dev)
+g = torch.linspace(-0.25, 0.25, 32, device=dev); o = torch.stack([g.repeat(32), g.repeat_interleave(32), torch.zeros(1024, device=dev)], 1).contiguous(); n = torch.tensor([[0, 0, 1.0]] * 1024, device=dev)
 for _ in range(3):
     r.render_transient(o, n, v, f, 20000, 0.625, 1.625, 2.0 ** -9)
 torch.cuda.synchronize()
