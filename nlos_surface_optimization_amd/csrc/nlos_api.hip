@@ -480,8 +480,8 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         long long h[8];
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h, c->status.p, sizeof(h), hipMemcpyDeviceToHost));
-        double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
-        std::fprintf(stderr, "[fwd stamps] setup %.1f%% count %.1f%% scan %.1f%% fill %.1f%% trace %.1f%% (sum %.3g cycles)\n", 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, tot);
+        std::fprintf(stderr, "[fwd counters] rays %lld  lane-iterations %lld (%.1f/ray)  wave-iterations %lld  lane-MT %lld (%.1f/ray)  wave-iterations-with-MT %lld\n",
+                     h[0], h[1], (double)h[1] / (double)(h[0] ? h[0] : 1), h[2], h[3], (double)h[3] / (double)(h[0] ? h[0] : 1), h[4]);
     }
 #endif
     if (!skip_pass1 && mode != NLOS_MODE_INTENSITY && fwd_refine > 1) {
