@@ -186,14 +186,14 @@ int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bo
     rc |= c->parent.ensure(sizeof(int) * n_nodes);
     rc |= c->arrive.ensure(sizeof(int) * (size_t)nF);
     rc |= c->box.ensure(sizeof(float) * 6 * n_nodes);
-    rc |= c->status.ensure(sizeof(int) * 16);
+    rc |= c->status.ensure(sizeof(int) * 64);
     rc |= c->nodes.ensure(sizeof(float4) * 2 * n_nodes);
     rc |= c->tris.ensure(sizeof(float4) * 4 * (size_t)nF);
     rc |= c->facerec.ensure(sizeof(float4) * 4 * (size_t)nF);
     rc |= c->face_id.ensure(sizeof(int) * (size_t)nF);
     rc |= c->tri_zmin.ensure(sizeof(float) * (size_t)nF);
     if (rc) return NLOS_ERR_HIP;
-    HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int) * 16, st));
+    HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int) * 64, st));
     nlos::BuildArgs b;
     b.vertices = V; b.faces = F; b.V = nV; b.F = nF;
     b.keys0 = c->keys0.as<uint32_t>(); b.keys1 = c->keys1.as<uint32_t>();
@@ -431,7 +431,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.force_bvh = a->force_bvh;
     fa.dbg = nullptr;
 #ifdef NLOS_FWD_STAMPS
-    HIP_TRY(hipMemsetAsync(c->status.p, 0, 16 * sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(c->status.p, 0, 64 * sizeof(int), st));
     fa.dbg = c->status.as<long long>();     // 8 x int64 (diagnostic build only)
 #endif
     fa.rows = nullptr;
@@ -477,11 +477,19 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     if (!skip_pass1) nlos::launch_forward(fa, st);
 #ifdef NLOS_FWD_STAMPS
     {
-        long long h[8];
+        long long h[24];
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h, c->status.p, sizeof(h), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[fwd counters] rays %lld  lane-iterations %lld (%.1f/ray)  wave-iterations %lld  lane-MT %lld (%.1f/ray)  wave-iterations-with-MT %lld\n",
-                     h[0], h[1], (double)h[1] / (double)(h[0] ? h[0] : 1), h[2], h[3], (double)h[3] / (double)(h[0] ? h[0] : 1), h[4]);
+        double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5]);
+        std::fprintf(stderr, "[fwd stamps] setup %.1f%% count %.1f%% scan %.1f%% fill %.1f%% live-buckets %.1f%% trace %.1f%%\n",
+                     100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot);
+        double tt = (double)(h[14] + h[15] + h[16] + h[17]);
+        std::fprintf(stderr, "[fwd trace shares] generate %.1f%% filter-scan %.1f%% exact-rounds %.1f%% histogram+vis %.1f%%\n",
+                     100 * h[14] / tt, 100 * h[15] / tt, 100 * h[16] / tt, 100 * h[17] / tt);
+        double rw = (double)h[8] / 64.0;
+        std::fprintf(stderr, "[fwd counters] rays %lld entries/source %.0f | scan: lane-it %.1f/ray, wave-it %.1f/ray-wave | queued %.2f/ray | exact rounds %.2f/ray-wave\n",
+                     h[8], (double)h[13] / (double)(L > 0 ? L : 1), (double)h[9] / (double)(h[8] ? h[8] : 1), (double)h[10] / rw,
+                     (double)h[11] / (double)(h[8] ? h[8] : 1), (double)h[12] / rw);
     }
 #endif
     if (!skip_pass1 && mode != NLOS_MODE_INTENSITY && fwd_refine > 1) {

@@ -322,6 +322,7 @@ __global__ __launch_bounds__(256) void k_forward(ForwardArgs a, int rows_in_lds)
 struct GridView {
     float gx0, gy0, inv_cw, inv_ch;   // cell = floor((m - g0) * inv_c)
     float inv_qx, inv_qy;             // quantised coordinate = floor((m - g0) * inv_q), 256 levels
+    float z0, inv_qz;                 // quantised depth = floor((z - z0) * inv_qz), 255 levels over the scene
     int R;
 };
 
@@ -343,15 +344,27 @@ __device__ __forceinline__ Proj2 project_tri(V3 o, V3 p0, V3 p1, V3 p2) {
     return q;
 }
 
-// projected bounding box, quantised outwards (one extra level each side), packed x0 | x1<<8 | y0<<16 | y1<<24
-__device__ __forceinline__ uint32_t quant_bbox(const GridView& g, const Proj2& q) {
+// Per-triangle filter word kept in LDS: projected bounding box, quantised outwards (one extra
+// level each side) to 1/256 of the grid extent, plus the smallest depth quantised downwards to
+// 1/255 of the scene's depth range:  x0:8 | w:4 | y0:8 | h:4 | zq:8.  A width/height of 15 means
+// "15 or more" and always passes.
+__device__ __forceinline__ uint32_t quant_filter(const GridView& g, const Proj2& q, float zmin_rel) {
     const float x0 = fminf(fminf(q.ax, q.bx), q.cx), x1 = fmaxf(fmaxf(q.ax, q.bx), q.cx);
     const float y0 = fminf(fminf(q.ay, q.by), q.cy), y1 = fmaxf(fmaxf(q.ay, q.by), q.cy);
     const int a0 = min(max((int)floorf((x0 - g.gx0) * g.inv_qx) - 1, 0), 255);
     const int a1 = min(max((int)floorf((x1 - g.gx0) * g.inv_qx) + 1, 0), 255);
     const int b0 = min(max((int)floorf((y0 - g.gy0) * g.inv_qy) - 1, 0), 255);
     const int b1 = min(max((int)floorf((y1 - g.gy0) * g.inv_qy) + 1, 0), 255);
-    return (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)b0 << 16) | ((uint32_t)b1 << 24);
+    const int w = min(a1 - a0, 15), h = min(b1 - b0, 15);
+    const int zq = min(max((int)floorf((zmin_rel - g.z0) * g.inv_qz) - 1, 0), 255);
+    return (uint32_t)a0 | ((uint32_t)w << 8) | ((uint32_t)b0 << 12) | ((uint32_t)h << 20) | ((uint32_t)zq << 24);
+}
+
+// does the triangle's filter word admit a ray at quantised slope (qx, qy) that ends at depth level rq?
+__device__ __forceinline__ bool filter_pass(uint32_t fw, uint32_t qx, uint32_t qy, uint32_t rq) {
+    const uint32_t x0 = fw & 255u, w = (fw >> 8) & 15u, y0 = (fw >> 12) & 255u, h = (fw >> 20) & 15u, zq = fw >> 24;
+    const uint32_t dx = qx - x0, dy = qy - y0;             // wraps to a huge value when q < 0-corner
+    return ((dx <= w) | ((w == 15u) & (qx >= x0))) & ((dy <= h) | ((h == 15u) & (qy >= y0))) & (zq <= rq);
 }
 
 // conservative rasterisation of a projected triangle: fn(xx, yy) for every overlapped cell
@@ -388,8 +401,9 @@ __device__ __forceinline__ void raster_tri(const GridView& g, const Proj2& q, Fn
     }
 }
 
+// two 512-thread workgroups per CU = 4 waves per SIMD: keep the kernel within 128 VGPRs
 template <int FEAT>
-__global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in_lds, int R, int cap) {
+__global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows_in_lds, int R, int cap) {
     // dynamic LDS: [ctl: ticket, bad, total, n_live (16 B)][row nbins f64][cells R*R+1 u32]
     //   [depth bound per 2x2 cells, R2*R2 u32][block masks nblk u64][block bases nblk+1 u32]
     //   [projected boxes F u32][live F u16][entries cap u16]
@@ -444,6 +458,8 @@ __global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in
         g.inv_ch = (float)R / (wy * 1.002f);
         g.inv_qx = 256.0f / (wx * 1.002f);
         g.inv_qy = 256.0f / (wy * 1.002f);
+        g.z0 = zr0;
+        g.inv_qz = 255.0f / fmaxf(zr1 - zr0, 1e-12f);
     }
 
     if (rows_in_lds)
@@ -496,8 +512,9 @@ __global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in
         for (int j = tid; j < F; j += NT) {
             const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
             const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
-            s_bbox[j] = quant_bbox(g, q);
-            const uint32_t zn = __float_as_uint(fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f));
+            const float zmin_rel = fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f);
+            s_bbox[j] = quant_filter(g, q, zmin_rel);
+            const uint32_t zn = __float_as_uint(zmin_rel);
             raster_tri(g, q, [&](int xx, int yy) {
                 if (zn <= s_zc[(yy >> 1) * R2 + (xx >> 1)]) atomicAdd(&s_cell[yy * R + xx], 1u);
             });
@@ -531,12 +548,7 @@ __global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in
     }
     __syncthreads();
     FWD_STAMP();   // 2: scans
-    // ---- live list + fill pass: s_cell[c] is the write cursor, afterwards the END of cell c --------
-    for (int b = wave; b < nblocks; b += nwaves) {
-        const unsigned long long m = s_mask[b];
-        if ((m >> lane) & 1ull)
-            s_live[s_base[b] + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((b << 6) + lane);
-    }
+    // ---- fill pass: s_cell[c] is the write cursor, afterwards the END of cell c ------------------
     if (frame_ok && s_ctl[1] == 0) {
         for (int j = tid; j < F; j += NT) {
             const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
@@ -552,7 +564,39 @@ __global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in
     }
     __syncthreads();
     FWD_STAMP();   // 3: fill pass
+    // ---- live list, bucketed by the length of the list of the face's centroid cell ----------------
+    // Cell lists have a heavy tail (mean 16, max > 60 entries) and the filter walk below is a
+    // lockstep loop: a wave is as slow as its longest list.  Handing out the live faces in
+    // buckets of similar list length (longest first) makes the 64 lists of a wave comparable.
     const bool use_grid = s_ctl[1] == 0;
+    auto face_bucket = [&](int j) -> int {
+        if (!use_grid) return 0;
+        const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
+        const float cxw = (q0.x + q0.w + q1.z) * (1.0f / 3.0f) - o.x, cyw = (q0.y + q1.x + q1.w) * (1.0f / 3.0f) - o.y;
+        const float iz = __builtin_amdgcn_rcpf((q0.z + q1.y + q2.x) * (1.0f / 3.0f) - o.z);
+        const int c = cell_coord(cyw * iz, g.gy0, g.inv_ch, R) * R + cell_coord(cxw * iz, g.gx0, g.inv_cw, R);
+        const uint32_t n = s_cell[c] - (c > 0 ? s_cell[c - 1] : 0u);
+        return 7 - (int)min(n >> 3, 7u);                    // bucket 0 = longest lists
+    };
+    if (tid < 16) s_scan[tid] = 0u;
+    __syncthreads();
+    for (int b = wave; b < nblocks; b += nwaves) {
+        if ((s_mask[b] >> lane) & 1ull) atomicAdd(&s_scan[face_bucket((b << 6) + lane)], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int q = 0; q < 8; ++q) { s_scan[8 + q] = run; run += s_scan[q]; }
+    }
+    __syncthreads();
+    for (int b = wave; b < nblocks; b += nwaves) {
+        if ((s_mask[b] >> lane) & 1ull) {
+            const int j = (b << 6) + lane;
+            s_live[atomicAdd(&s_scan[8 + face_bucket(j)], 1u)] = (uint16_t)j;
+        }
+    }
+    __syncthreads();
+    FWD_STAMP();   // 4: bucketed live list
     const int n_live = s_ctl[3];
     const int live_blocks = (n_live + 63) >> 6;
 
@@ -571,6 +615,15 @@ __global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in
     const int spt = a.sp.spt;
     const float lb = a.sp.lb, ub = a.sp.ub, res = a.sp.res;
     double* grow = a.rows ? a.rows + (size_t)l * nbins : nullptr;
+#ifdef NLOS_FWD_STAMPS
+    unsigned long long c_rays = 0, c_pairs = 0, c_iters = 0, c_mt = 0, c_mtw = 0;   // diagnostic build only
+    long long tg = 0, ts = 0, tx = 0, th = 0, tmark = 0;
+#define TMARK() (tmark = clock64())
+#define TACC(v) do { long long now_ = clock64(); v += now_ - tmark; tmark = now_; } while (0)
+#else
+#define TMARK() do { } while (0)
+#define TACC(v) do { } while (0)
+#endif
     uint32_t* wq = s_queue + wave * 128;                 // this wave's pair queue
     uint32_t* wocc = s_queue + nwaves * 128 + wave * 2;  // this wave's 64-bit occlusion mask
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -588,6 +641,7 @@ __global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in
         uint32_t word = 0;
         double inten = 0.0;
         for (int s = 0; s < spt; ++s) {
+            TMARK();
             Geo gg;
             float t_self = 0.0f;
             bool ok = has_face;
@@ -610,19 +664,28 @@ __global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in
                 ok = !occluded(a.sc.nodes, a.sc.n_nodes, a.sc.tris, a.sc.face_id, o, gg.dir, t_self, j, f.fid);
 
             // ---- stage 1 + 2 (wave-synchronous; every lane takes part) ----
-            uint32_t e = 0, e1 = 0, qx = 0, qy = 0;
+            uint32_t e = 0, n_ent = 0, qpack = 0;
             if (grid_ray) {
                 const float iz = __builtin_amdgcn_rcpf(gg.dir.z);   // lookups only: 1-ulp rcp is fine
                 const float mx = gg.dir.x * iz, my = gg.dir.y * iz;
                 const int c = cell_coord(my, g.gy0, g.inv_ch, R) * R + cell_coord(mx, g.gx0, g.inv_cw, R);
-                qx = (uint32_t)min(max((int)floorf((mx - g.gx0) * g.inv_qx), 0), 255);
-                qy = (uint32_t)min(max((int)floorf((my - g.gy0) * g.inv_qy), 0), 255);
-                e1 = s_cell[c];
+                const uint32_t qx = (uint32_t)min(max((int)floorf((mx - g.gx0) * g.inv_qx), 0), 255);
+                const uint32_t qy = (uint32_t)min(max((int)floorf((my - g.gy0) * g.inv_qy), 0), 255);
+                // depth level of the own-face hit, rounded up: anything quantised deeper cannot occlude
+                const float zs = t_self * gg.dir.z;
+                const uint32_t rq = (uint32_t)min(max((int)floorf((zs * 1.00002f - g.z0) * g.inv_qz) + 1, 0), 255);
+                qpack = qx | (qy << 8) | (rq << 16);
+                const uint32_t e1 = s_cell[c];
                 e = c > 0 ? s_cell[c - 1] : 0u;
+                n_ent = e1 - e;
             }
             if (lane < 2) wocc[lane] = 0u;
+            TACC(tg);
             int qn = 0;                                        // wave-uniform
             auto exact_round = [&](int n) {
+#ifdef NLOS_FWD_STAMPS
+                if (lane == 0) c_mtw += 1;
+#endif
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const uint32_t pr = wq[lane < n ? lane : 0];
@@ -638,21 +701,34 @@ __global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             };
+            // lockstep filter walk (LDS only): entry index + packed box/depth word.  (A fully
+            // flattened walk -- pairs spread evenly over the lanes with a prefix-sum owner search --
+            // halves the iterations but its dependent ds_bpermute chain makes it slower; measured.)
+#ifdef NLOS_FWD_STAMPS
+            if (grid_ray) c_rays += 1;
+#endif
+            const uint32_t e1 = e + n_ent;
+            const uint32_t qx = qpack & 255u, qy = (qpack >> 8) & 255u, rq = qpack >> 16;
             while (__any(e < e1)) {
                 bool pass = false;
                 int k = 0;
                 if (e < e1) {
                     k = (int)s_ent[e++];
-                    const uint32_t bb = s_bbox[k];
-                    pass = (qx >= (bb & 255u)) & (qx <= ((bb >> 8) & 255u)) & (qy >= ((bb >> 16) & 255u)) &
-                           (qy <= (bb >> 24)) & (k != j);
+                    pass = filter_pass(s_bbox[k], qx, qy, rq) & (k != j);
                 }
+#ifdef NLOS_FWD_STAMPS
+                if (e <= e1 && grid_ray) c_pairs += 1;
+                if (lane == 0) c_iters += 1;
+                if (pass) c_mt += 1;
+#endif
                 const unsigned long long m = __ballot(pass);
                 if (m) {
                     if (pass) wq[qn + __popcll(m & lt_mask)] = ((uint32_t)lane << 16) | (uint32_t)k;
                     qn += __popcll(m);
                     if (qn >= 64) {
+                        TACC(ts);
                         exact_round(64);
+                        TACC(tx);
                         qn -= 64;
                         const uint32_t mv = wq[64 + (lane < qn ? lane : 0)];
                         __builtin_amdgcn_wave_barrier();
@@ -660,7 +736,9 @@ __global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in
                     }
                 }
             }
+            TACC(ts);
             if (qn > 0) exact_round(qn);
+            TACC(tx);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (grid_ray) ok = ((wocc[lane >> 5] >> (lane & 31)) & 1u) == 0u;
             __builtin_amdgcn_wave_barrier();
@@ -682,10 +760,27 @@ __global__ __launch_bounds__(512) void k_forward_grid(ForwardArgs a, int rows_in
                 if (visp) visp[(size_t)(s >> 5) * F] = word;
                 word = 0;
             }
+            TACC(th);
         }
         if (a.mode_intensity && has_face && inten != 0.0) unsafeAtomicAdd(&a.intensity[f.fid], inten);
     }
-    FWD_STAMP();   // 4: sample + trace + histogram
+#ifdef NLOS_FWD_STAMPS
+    if (a.dbg) {   // diagnostic build only: work counters -> a.dbg[8..12]
+        atomicAdd((unsigned long long*)&a.dbg[8], c_rays);
+        atomicAdd((unsigned long long*)&a.dbg[9], c_pairs);
+        atomicAdd((unsigned long long*)&a.dbg[10], c_iters);
+        atomicAdd((unsigned long long*)&a.dbg[11], c_mt);
+        atomicAdd((unsigned long long*)&a.dbg[12], c_mtw);
+        if (tid == 0) atomicAdd((unsigned long long*)&a.dbg[13], (unsigned long long)s_ctl[2]);
+        if (lane == 0) {
+            atomicAdd((unsigned long long*)&a.dbg[14], (unsigned long long)tg);
+            atomicAdd((unsigned long long*)&a.dbg[15], (unsigned long long)ts);
+            atomicAdd((unsigned long long*)&a.dbg[16], (unsigned long long)tx);
+            atomicAdd((unsigned long long*)&a.dbg[17], (unsigned long long)th);
+        }
+    }
+#endif
+    FWD_STAMP();   // 5: sample + trace + histogram
     if (rows_in_lds && grow) {
         __syncthreads();
         for (int i = tid; i < nbins; i += NT) grow[i] = s_row[i];
