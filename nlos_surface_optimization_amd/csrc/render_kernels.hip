@@ -569,16 +569,25 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     // lockstep loop: a wave is as slow as its longest list.  Handing out the live faces in
     // buckets of similar list length (longest first) makes the 64 lists of a wave comparable.
     const bool use_grid = s_ctl[1] == 0;
+    constexpr int NB = 16;                                   // buckets of 4 entries
     auto face_bucket = [&](int j) -> int {
         if (!use_grid) return 0;
+        // longest list among the cells under the face's projected bounding box
         const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
-        const float cxw = (q0.x + q0.w + q1.z) * (1.0f / 3.0f) - o.x, cyw = (q0.y + q1.x + q1.w) * (1.0f / 3.0f) - o.y;
-        const float iz = __builtin_amdgcn_rcpf((q0.z + q1.y + q2.x) * (1.0f / 3.0f) - o.z);
-        const int c = cell_coord(cyw * iz, g.gy0, g.inv_ch, R) * R + cell_coord(cxw * iz, g.gx0, g.inv_cw, R);
-        const uint32_t n = s_cell[c] - (c > 0 ? s_cell[c - 1] : 0u);
-        return 7 - (int)min(n >> 3, 7u);                    // bucket 0 = longest lists
+        const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
+        const int cx0 = cell_coord(fminf(fminf(q.ax, q.bx), q.cx), g.gx0, g.inv_cw, R);
+        const int cx1 = cell_coord(fmaxf(fmaxf(q.ax, q.bx), q.cx), g.gx0, g.inv_cw, R);
+        const int cy0 = cell_coord(fminf(fminf(q.ay, q.by), q.cy), g.gy0, g.inv_ch, R);
+        const int cy1 = cell_coord(fmaxf(fmaxf(q.ay, q.by), q.cy), g.gy0, g.inv_ch, R);
+        uint32_t n = 0;
+        for (int yy = cy0; yy <= cy1; ++yy)
+            for (int xx = cx0; xx <= cx1; ++xx) {
+                const int c = yy * R + xx;
+                n = max(n, s_cell[c] - (c > 0 ? s_cell[c - 1] : 0u));
+            }
+        return (NB - 1) - (int)min(n >> 2, (uint32_t)(NB - 1));   // bucket 0 = longest lists
     };
-    if (tid < 16) s_scan[tid] = 0u;
+    if (tid < 2 * NB) s_scan[tid] = 0u;
     __syncthreads();
     for (int b = wave; b < nblocks; b += nwaves) {
         if ((s_mask[b] >> lane) & 1ull) atomicAdd(&s_scan[face_bucket((b << 6) + lane)], 1u);
@@ -586,13 +595,13 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     __syncthreads();
     if (tid == 0) {
         uint32_t run = 0;
-        for (int q = 0; q < 8; ++q) { s_scan[8 + q] = run; run += s_scan[q]; }
+        for (int q = 0; q < NB; ++q) { s_scan[NB + q] = run; run += s_scan[q]; }
     }
     __syncthreads();
     for (int b = wave; b < nblocks; b += nwaves) {
         if ((s_mask[b] >> lane) & 1ull) {
             const int j = (b << 6) + lane;
-            s_live[atomicAdd(&s_scan[8 + face_bucket(j)], 1u)] = (uint16_t)j;
+            s_live[atomicAdd(&s_scan[NB + face_bucket(j)], 1u)] = (uint16_t)j;
         }
     }
     __syncthreads();
@@ -954,8 +963,9 @@ __device__ __forceinline__ void grouped_taps(const TapTables& tt, const double* 
 
 // MODE 0: per-vertex gradient [V,3]; 1: scalar d/d albedo; 2: scalar d/d alpha (GGX);
 //      3: single-vertex per-bin gradient [T,3]
+// two 512-thread workgroups per CU (LDS: ~76 KB each) need <= 128 VGPRs
 template <int FEAT, int MODE>
-__global__ __launch_bounds__(512) void k_gradient(GradientArgs a) {
+__global__ __launch_bounds__(512, 4) void k_gradient(GradientArgs a) {
     extern __shared__ double s_mem[];       // [ticket (8 B)][diff row T][tap tables 3K+2][grad 3V][masks][bases][live]
     int* s_next = reinterpret_cast<int*>(s_mem);
     const int T = a.sp.nbins;
