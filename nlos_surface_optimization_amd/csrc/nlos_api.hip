@@ -79,7 +79,7 @@ struct nlos_ctx {
     DevBuf nodes, tris, facerec, face_id, tri_zmin;
     int built_F = -1, built_V = -1;
     // render scratch
-    DevBuf vis, diff, fine, taps, rows_tmp, grad_tmp;
+    DevBuf vis, diff, fine, taps, rows_tmp, grad_tmp, live;
     int tap_refine = -1, tap_sigma = -1; float tap_res = -1.0f; int tap_kind = -1;
     // host-pointer path staging
     DevBuf io[12];
@@ -278,7 +278,7 @@ void nlos_ctx_destroy(nlos_ctx* c) {
     DeviceGuard g(c->device);
     DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                      &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp};
+                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live};
     for (DevBuf* b : all) b->release();
     for (DevBuf& b : c->io) b.release();
     for (hipEvent_t& e : c->ring) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
@@ -289,7 +289,7 @@ int64_t nlos_ctx_scratch_bytes(const nlos_ctx* c) {
     if (!c) return 0;
     const DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                            &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp};
+                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live};
     int64_t s = 0;
     for (const DevBuf* b : all) s += (int64_t)b->cap;
     for (const DevBuf& b : c->io) s += (int64_t)b.cap;
@@ -430,6 +430,12 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.intensity = a->intensity; fa.mode_intensity = mode == NLOS_MODE_INTENSITY ? 1 : 0;
     fa.force_bvh = a->force_bvh;
     fa.dbg = nullptr;
+    fa.live = nullptr;
+    if (nF <= 65535 && !a->force_bvh) {
+        rc = c->live.ensure(sizeof(uint16_t) * (size_t)(L > 0 ? L : 1) * nF + 16);
+        if (rc) return rc;
+        fa.live = c->live.as<uint16_t>();
+    }
 #ifdef NLOS_FWD_STAMPS
     HIP_TRY(hipMemsetAsync(c->status.p, 0, 64 * sizeof(int), st));
     fa.dbg = c->status.as<long long>();     // 8 x int64 (diagnostic build only)

@@ -322,7 +322,8 @@ __global__ __launch_bounds__(256) void k_forward(ForwardArgs a, int rows_in_lds)
 struct GridView {
     float gx0, gy0, inv_cw, inv_ch;   // cell = floor((m - g0) * inv_c)
     float inv_qx, inv_qy;             // quantised coordinate = floor((m - g0) * inv_q), 256 levels
-    float z0, inv_qz;                 // quantised depth = floor((z - z0) * inv_qz), 255 levels over the scene
+    float z0, inv_qz;                 // quantised depth = floor((z - z0) * inv_qz), zmax levels over the scene
+    int ib, zmax;                     // entry = index (ib bits) | x0:3 x1:3 y0:3 y1:3 | depth (32-12-ib bits)
     int R;
 };
 
@@ -344,27 +345,18 @@ __device__ __forceinline__ Proj2 project_tri(V3 o, V3 p0, V3 p1, V3 p2) {
     return q;
 }
 
-// Per-triangle filter word kept in LDS: projected bounding box, quantised outwards (one extra
-// level each side) to 1/256 of the grid extent, plus the smallest depth quantised downwards to
-// 1/255 of the scene's depth range:  x0:8 | w:4 | y0:8 | h:4 | zq:8.  A width/height of 15 means
-// "15 or more" and always passes.
-__device__ __forceinline__ uint32_t quant_filter(const GridView& g, const Proj2& q, float zmin_rel) {
-    const float x0 = fminf(fminf(q.ax, q.bx), q.cx), x1 = fmaxf(fmaxf(q.ax, q.bx), q.cx);
-    const float y0 = fminf(fminf(q.ay, q.by), q.cy), y1 = fmaxf(fmaxf(q.ay, q.by), q.cy);
-    const int a0 = min(max((int)floorf((x0 - g.gx0) * g.inv_qx) - 1, 0), 255);
-    const int a1 = min(max((int)floorf((x1 - g.gx0) * g.inv_qx) + 1, 0), 255);
-    const int b0 = min(max((int)floorf((y0 - g.gy0) * g.inv_qy) - 1, 0), 255);
-    const int b1 = min(max((int)floorf((y1 - g.gy0) * g.inv_qy) + 1, 0), 255);
-    const int w = min(a1 - a0, 15), h = min(b1 - b0, 15);
-    const int zq = min(max((int)floorf((zmin_rel - g.z0) * g.inv_qz) - 1, 0), 255);
-    return (uint32_t)a0 | ((uint32_t)w << 8) | ((uint32_t)b0 << 12) | ((uint32_t)h << 20) | ((uint32_t)zq << 24);
-}
+// Cell-list entry (32 bit, LDS): triangle index in the low `ib` bits, then the triangle's projected
+// bounding box clipped to THIS cell in eighths of the cell (x0, x1, y0, y1: 3 bits each, rounded
+// outwards by one level), then its smallest depth quantised downwards over the scene's depth range.
+// One LDS read per candidate gives everything the filter needs.
+struct BBoxF { float x0, x1, y0, y1; };
 
-// does the triangle's filter word admit a ray at quantised slope (qx, qy) that ends at depth level rq?
-__device__ __forceinline__ bool filter_pass(uint32_t fw, uint32_t qx, uint32_t qy, uint32_t rq) {
-    const uint32_t x0 = fw & 255u, w = (fw >> 8) & 15u, y0 = (fw >> 12) & 255u, h = (fw >> 20) & 15u, zq = fw >> 24;
-    const uint32_t dx = qx - x0, dy = qy - y0;             // wraps to a huge value when q < 0-corner
-    return ((dx <= w) | ((w == 15u) & (qx >= x0))) & ((dy <= h) | ((h == 15u) & (qy >= y0))) & (zq <= rq);
+__device__ __forceinline__ uint32_t make_entry(const GridView& g, const BBoxF& bb, int xx, int yy, uint32_t zq, int k) {
+    const float fx0 = ((bb.x0 - g.gx0) * g.inv_cw - (float)xx) * 8.0f, fx1 = ((bb.x1 - g.gx0) * g.inv_cw - (float)xx) * 8.0f;
+    const float fy0 = ((bb.y0 - g.gy0) * g.inv_ch - (float)yy) * 8.0f, fy1 = ((bb.y1 - g.gy0) * g.inv_ch - (float)yy) * 8.0f;
+    const uint32_t a0 = (uint32_t)min(max((int)floorf(fx0) - 1, 0), 7), a1 = (uint32_t)min(max((int)floorf(fx1) + 1, 0), 7);
+    const uint32_t b0 = (uint32_t)min(max((int)floorf(fy0) - 1, 0), 7), b1 = (uint32_t)min(max((int)floorf(fy1) + 1, 0), 7);
+    return (uint32_t)k | (((a0) | (a1 << 3) | (b0 << 6) | (b1 << 9) | (zq << 12)) << g.ib);
 }
 
 // conservative rasterisation of a projected triangle: fn(xx, yy) for every overlapped cell
@@ -405,8 +397,9 @@ __device__ __forceinline__ void raster_tri(const GridView& g, const Proj2& q, Fn
 template <int FEAT>
 __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows_in_lds, int R, int cap) {
     // dynamic LDS: [ctl: ticket, bad, total, n_live (16 B)][row nbins f64][cells R*R+1 u32]
-    //   [depth bound per 2x2 cells, R2*R2 u32][block masks nblk u64][block bases nblk+1 u32]
-    //   [projected boxes F u32][live F u16][entries cap u16]
+    //   [union { build: depth bound per 2x2 cells R2*R2 u32, block masks nblk u64 ;
+    //            trace: 8 waves x (128 queued pairs + 2 mask words) }][entries cap u32]
+    // (the bucketed live-face list lives in global scratch: it is read once per 64-face block)
     extern __shared__ double s_lds[];
     int* s_ctl = reinterpret_cast<int*>(s_lds);
     double* s_row = s_lds + 2;
@@ -416,13 +409,13 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     const int F = a.sc.F;
     const int nblocks = (F + 63) >> 6;
     uint32_t* s_cell = reinterpret_cast<uint32_t*>(s_row + (rows_in_lds ? nbins : 0));
-    uint32_t* s_zc = s_cell + ((ncell + 2) & ~1);
+    uint32_t* s_union = s_cell + ((ncell + 2) & ~1);
+    uint32_t* s_zc = s_union;                                                   // build phase
     unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(s_zc + ((R2 * R2 + 1) & ~1));
-    uint32_t* s_base = reinterpret_cast<uint32_t*>(s_mask + nblocks);
-    uint32_t* s_bbox = s_base + ((nblocks + 2) & ~1);
-    uint32_t* s_queue = s_bbox + F;                       // 8 waves x (128 pairs + 2 mask words)
-    uint16_t* s_live = reinterpret_cast<uint16_t*>(s_queue + 8 * 130);
-    uint16_t* s_ent = s_live + ((F + 3) & ~3);
+    uint32_t* s_queue = s_union;                                                // trace phase
+    const int union_words = max(((R2 * R2 + 1) & ~1) + 2 * nblocks, 8 * 130);
+    uint32_t* s_ent = s_union + ((union_words + 1) & ~1);
+    uint16_t* g_live = a.live + (size_t)blockIdx.x * F;
     __shared__ uint32_t s_scan[512];
 
     const int l = blockIdx.x;
@@ -458,8 +451,10 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
         g.inv_ch = (float)R / (wy * 1.002f);
         g.inv_qx = 256.0f / (wx * 1.002f);
         g.inv_qy = 256.0f / (wy * 1.002f);
+        g.ib = F <= 8192 ? 13 : 16;
+        g.zmax = (1 << (20 - g.ib)) - 1;
         g.z0 = zr0;
-        g.inv_qz = 255.0f / fmaxf(zr1 - zr0, 1e-12f);
+        g.inv_qz = (float)g.zmax / fmaxf(zr1 - zr0, 1e-12f);
     }
 
     if (rows_in_lds)
@@ -508,13 +503,11 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     FWD_STAMP();   // 0: setup + live-face masks + depth bounds
 
     if (frame_ok) {
-        // ---- counting pass (also fills the projected-box table) ------------------------------------
+        // ---- counting pass ---------------------------------------------------------------------------
         for (int j = tid; j < F; j += NT) {
             const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
             const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
-            const float zmin_rel = fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f);
-            s_bbox[j] = quant_filter(g, q, zmin_rel);
-            const uint32_t zn = __float_as_uint(zmin_rel);
+            const uint32_t zn = __float_as_uint(fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f));
             raster_tri(g, q, [&](int xx, int yy) {
                 if (zn <= s_zc[(yy >> 1) * R2 + (xx >> 1)]) atomicAdd(&s_cell[yy * R + xx], 1u);
             });
@@ -524,8 +517,7 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     FWD_STAMP();   // 1: counting pass
     if (tid == 0) {
         uint32_t run = 0;
-        for (int b = 0; b < nblocks; ++b) { s_base[b] = run; run += (uint32_t)__popcll(s_mask[b]); }
-        s_base[nblocks] = run;
+        for (int b = 0; b < nblocks; ++b) run += (uint32_t)__popcll(s_mask[b]);
         s_ctl[3] = (int)run;
     }
     if (frame_ok) {
@@ -553,11 +545,16 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
         for (int j = tid; j < F; j += NT) {
             const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
             const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
-            const uint32_t zn = __float_as_uint(fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f));
+            const float zmin_rel = fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f);
+            const uint32_t zn = __float_as_uint(zmin_rel);
+            const uint32_t zq = (uint32_t)min(max((int)floorf((zmin_rel - g.z0) * g.inv_qz) - 1, 0), g.zmax);
+            BBoxF bb;
+            bb.x0 = fminf(fminf(q.ax, q.bx), q.cx); bb.x1 = fmaxf(fmaxf(q.ax, q.bx), q.cx);
+            bb.y0 = fminf(fminf(q.ay, q.by), q.cy); bb.y1 = fmaxf(fmaxf(q.ay, q.by), q.cy);
             raster_tri(g, q, [&](int xx, int yy) {
                 if (zn <= s_zc[(yy >> 1) * R2 + (xx >> 1)]) {
                     uint32_t pos = atomicAdd(&s_cell[yy * R + xx], 1u);
-                    s_ent[pos] = (uint16_t)j;
+                    s_ent[pos] = make_entry(g, bb, xx, yy, zq, j);
                 }
             });
         }
@@ -601,7 +598,7 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     for (int b = wave; b < nblocks; b += nwaves) {
         if ((s_mask[b] >> lane) & 1ull) {
             const int j = (b << 6) + lane;
-            s_live[atomicAdd(&s_scan[NB + face_bucket(j)], 1u)] = (uint16_t)j;
+            g_live[atomicAdd(&s_scan[NB + face_bucket(j)], 1u)] = (uint16_t)j;
         }
     }
     __syncthreads();
@@ -633,7 +630,7 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
 #define TMARK() do { } while (0)
 #define TACC(v) do { } while (0)
 #endif
-    uint32_t* wq = s_queue + wave * 128;                 // this wave's pair queue
+    uint32_t* wq = s_queue + wave * 128;                 // this wave's pair queue (aliases the build-phase tables)
     uint32_t* wocc = s_queue + nwaves * 128 + wave * 2;  // this wave's 64-bit occlusion mask
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
@@ -642,7 +639,7 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
         if (b >= live_blocks) break;
         const int li = (b << 6) + lane;
         const bool has_face = li < n_live;
-        const int j = has_face ? (int)s_live[li] : 0;
+        const int j = has_face ? (int)g_live[li] : 0;
         const Face f = load_face(a.sc.facerec, j);
         uint32_t* visp = (a.vis && has_face) ? a.vis + ((size_t)l * a.vis_words) * F + j : nullptr;
         const Tri tr = load_tri(a.sc.tris, j);
@@ -673,20 +670,19 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
                 ok = !occluded(a.sc.nodes, a.sc.n_nodes, a.sc.tris, a.sc.face_id, o, gg.dir, t_self, j, f.fid);
 
             // ---- stage 1 + 2 (wave-synchronous; every lane takes part) ----
-            uint32_t e = 0, n_ent = 0, qpack = 0;
+            uint32_t e = 0, e1 = 0, sx = 0, sy = 0, rq = 0;
             if (grid_ray) {
                 const float iz = __builtin_amdgcn_rcpf(gg.dir.z);   // lookups only: 1-ulp rcp is fine
-                const float mx = gg.dir.x * iz, my = gg.dir.y * iz;
-                const int c = cell_coord(my, g.gy0, g.inv_ch, R) * R + cell_coord(mx, g.gx0, g.inv_cw, R);
-                const uint32_t qx = (uint32_t)min(max((int)floorf((mx - g.gx0) * g.inv_qx), 0), 255);
-                const uint32_t qy = (uint32_t)min(max((int)floorf((my - g.gy0) * g.inv_qy), 0), 255);
+                const float ux = (gg.dir.x * iz - g.gx0) * g.inv_cw, uy = (gg.dir.y * iz - g.gy0) * g.inv_ch;
+                const int cxx = min(max((int)floorf(ux), 0), R - 1), cyy = min(max((int)floorf(uy), 0), R - 1);
+                sx = (uint32_t)min(max((int)floorf((ux - (float)cxx) * 8.0f), 0), 7);
+                sy = (uint32_t)min(max((int)floorf((uy - (float)cyy) * 8.0f), 0), 7);
                 // depth level of the own-face hit, rounded up: anything quantised deeper cannot occlude
                 const float zs = t_self * gg.dir.z;
-                const uint32_t rq = (uint32_t)min(max((int)floorf((zs * 1.00002f - g.z0) * g.inv_qz) + 1, 0), 255);
-                qpack = qx | (qy << 8) | (rq << 16);
-                const uint32_t e1 = s_cell[c];
+                rq = (uint32_t)min(max((int)floorf((zs * 1.00002f - g.z0) * g.inv_qz) + 1, 0), g.zmax);
+                const int c = cyy * R + cxx;
+                e1 = s_cell[c];
                 e = c > 0 ? s_cell[c - 1] : 0u;
-                n_ent = e1 - e;
             }
             if (lane < 2) wocc[lane] = 0u;
             TACC(tg);
@@ -716,14 +712,16 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
 #ifdef NLOS_FWD_STAMPS
             if (grid_ray) c_rays += 1;
 #endif
-            const uint32_t e1 = e + n_ent;
-            const uint32_t qx = qpack & 255u, qy = (qpack >> 8) & 255u, rq = qpack >> 16;
+            const uint32_t imask = (1u << g.ib) - 1u;
             while (__any(e < e1)) {
                 bool pass = false;
                 int k = 0;
                 if (e < e1) {
-                    k = (int)s_ent[e++];
-                    pass = filter_pass(s_bbox[k], qx, qy, rq) & (k != j);
+                    const uint32_t w = s_ent[e++];
+                    const uint32_t fw = w >> g.ib;
+                    k = (int)(w & imask);
+                    pass = (sx >= (fw & 7u)) & (sx <= ((fw >> 3) & 7u)) & (sy >= ((fw >> 6) & 7u)) &
+                           (sy <= ((fw >> 9) & 7u)) & ((fw >> 12) <= rq) & (k != j);
                 }
 #ifdef NLOS_FWD_STAMPS
                 if (e <= e1 && grid_ray) c_pairs += 1;
@@ -1201,13 +1199,13 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
     R = std::min(std::max(R, 8), 96);
     const size_t nblk = ((size_t)a.sc.F + 63) / 64;
     const size_t R2 = ((size_t)R + 1) / 2;
+    size_t union_words = ((R2 * R2 + 1) & ~(size_t)1) + 2 * nblk;
+    if (union_words < 8 * 130) union_words = 8 * 130;
     const size_t fixed = 16 + (rows_in_lds ? (size_t)a.sp.nbins * sizeof(double) : 0) + (((size_t)R * R + 2) & ~(size_t)1) * 4 +
-                         ((R2 * R2 + 1) & ~(size_t)1) * 4 + nblk * 8 + ((nblk + 2) & ~(size_t)1) * 4 + (size_t)a.sc.F * 4 + 8 * 130 * 4 +
-                         (((size_t)a.sc.F + 3) & ~(size_t)3) * 2;
-    if (fixed + 2 * 2 * (size_t)a.sc.F > kGridLdsBudget) return false;      // want room for >= 2 entries per face
-    size_t cap = (kGridLdsBudget - fixed) / 2;
-    if (cap > 65535) cap = 65535;
-    const size_t lds = fixed + cap * 2;
+                         ((union_words + 1) & ~(size_t)1) * 4;
+    if (fixed + 4 * 2 * (size_t)a.sc.F > kGridLdsBudget || !a.live) return false;      // want room for >= 2 entries per face
+    size_t cap = (kGridLdsBudget - fixed) / 4;
+    const size_t lds = fixed + cap * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT>), dim3(a.src.L), dim3(512), lds, stream, a, rows_in_lds, R,
