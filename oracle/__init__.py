@@ -170,6 +170,35 @@ def render_gradient(origin, normal, v, f, num_sample, lb, ub, res, data, weight,
     return transient, gradient, path
 
 
+def render_nonconfocal(laser, laser_normal, sensor, sensor_normal, v, f, num_sample, lb, ub, res,
+                       data=None, weight=None, refine=10, sigma_bin=1, testing_flag=1, loss_flag=0,
+                       vnormal=None, albedo=None, gradient=None, **kw):
+    """Row N: (laser[i], sensor[i]) pairs. Returns (transient, gradient or None, pathlengths)."""
+    laser, laser_normal, sensor, sensor_normal = _f32(laser), _f32(laser_normal), _f32(sensor), _f32(sensor_normal)
+    v, f, vnormal, albedo = _f32(v), _i32(f), _f32(vnormal), _f32(albedo)
+    P, T = laser.shape[0], num_bins(lb, ub, res)
+    transient = np.zeros((P, T), dtype=np.float64)
+    path = np.zeros(T, dtype=np.float64)
+    if data is not None:
+        data = _f64(data)
+        weight = _f64(np.ones_like(data) if weight is None else weight)
+        if gradient is None:
+            gradient = np.zeros((v.shape[0], 3), dtype=np.float64)
+    o = make_opts(**kw)
+    fn = lib().nlos_oracle_render_nonconfocal
+    fn.argtypes = ([ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                   ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p])
+    rc = fn(_p(data), _p(weight), _p(laser), _p(laser_normal), _p(sensor), _p(sensor_normal), P,
+            _p(v), v.shape[0], _p(vnormal), _p(albedo), _p(f), f.shape[0], int(num_sample), lb, ub, res,
+            _p(transient), _p(path), _p(gradient) if data is not None else None, refine, sigma_bin,
+            testing_flag, loss_flag, ctypes.byref(o))
+    if rc:
+        raise ValueError("oracle render_nonconfocal failed rc=%d" % rc)
+    return transient, (gradient if data is not None else None), path
+
+
 def render_gradient_scalar(origin, normal, v, f, num_sample, lb, ub, res, data, weight,
                            refine=10, sigma_bin=1, loss_flag=0, albedo=None, wrt_alpha=False, **kw):
     origin, normal, v, f = _f32(origin), _f32(normal), _f32(v), _i32(f)

@@ -1072,6 +1072,237 @@ int nlos_oracle_render_gradient_v1(const double *data, const float *origin, int 
     return 0;
 }
 
+/* ------------------------------------------------------------ non-confocal */
+/* Row N: laser point a != sensor point b.  The reference has no native
+ * kernel for it; its prototypes (transient_rendering_python/rendering.py:37-93, angular sampling;
+ * mesh_optimization/rendering.py:739-797) fix the geometry -- the surface point must be the
+ * nearest hit seen from the laser AND visible from the sensor, path length d1 + d2 -- and this
+ * restatement keeps the v2 conventions of rows F/G (stratified samples per (pair, face), wall
+ * cosines, clamped form factors, bin = floor((d1 + d2 - lb)/res)), so that a == b reproduces the
+ * confocal rows: the forward pass bit for bit, the gradient up to fp32 rounding of
+ *     t1 = alb * (ff_b * grad ff_a + ff_a * grad ff_b),  grad ff = (n_o c3 - n c2 - 4 dir c2 c3)/d^3
+ * against  2 alb c2 c3 (...) / h^5. */
+typedef struct { float u, v, w, d1, d2; v3 dirA, dirB, n; float alb; } geo_nc_t;
+
+static inline int accept_sample_nc(const task_t *t, v3 b, const scene_t *sc, int f, int accel,
+                                   float S, float T, float lb, float ub, geo_nc_t *g) {
+    float sq = sqrtf(T);
+    float u = 1 - sq, v = (1 - S) * sq, w = S * sq;
+    v3 p = bary3(u, t->p0, v, t->p1, w, t->p2);
+    /* laser leg: identical to accept_sample() */
+    v3 dA = sub3(p, t->o);
+    v3 dirA = scl3(dA, 1.0f / sqrtf(dot3(dA, dA)));
+    hit_t hA = closest_hit(sc, t->o, dirA, accel);
+    if (hA.prim != f) return 0;
+    g->v = hA.u; g->w = hA.v; g->u = 1.0f - g->v - g->w;
+    v3 qA = bary3(g->u, t->p0, g->v, t->p1, g->w, t->p2);
+    v3 eA = sub3(qA, t->o);
+    g->d1 = sqrtf(dot3(eA, eA));
+    /* sensor leg: same construction from b towards the same stratified point */
+    v3 dB = sub3(p, b);
+    v3 dirB = scl3(dB, 1.0f / sqrtf(dot3(dB, dB)));
+    hit_t hB = closest_hit(sc, b, dirB, accel);
+    if (hB.prim != f) return 0;
+    v3 qB = bary3(1.0f - hB.u - hB.v, t->p0, hB.u, t->p1, hB.v, t->p2);
+    v3 eB = sub3(qB, b);
+    g->d2 = sqrtf(dot3(eB, eB));
+    float tot = g->d1 + g->d2;
+    if (!((tot <= ub) && (tot >= lb))) return 0;
+    g->dirA = dirA; g->dirB = dirB;
+    g->n = t->fn;
+    if (t->has_vn) g->n = bary3(g->u, t->n0, g->v, t->n1, g->w, t->n2);
+    g->alb = 1.0f;
+    if (t->has_alb) g->alb = g->u * t->a0 + g->v * t->a1 + g->w * t->a2;
+    return 1;
+}
+
+static void forward_task_nc(const scene_t *sc, const float *laser, const float *lnormal,
+                            const float *sensor, const float *snormal, const float *vnormal,
+                            const float *albedo, int l, int f, float lb, float ub, float res,
+                            int spt, int nbins, double *row, const nlos_oracle_opts *op) {
+    task_t t;
+    task_setup(&t, sc, laser, lnormal, l, f, vnormal, albedo);
+    if (t.degenerate) return;
+    const v3 b = ld3(sensor + 3 * (size_t)l), bn = ld3(snormal + 3 * (size_t)l);
+    uint64_t kbase = (((uint64_t)(op->source_offset + l)) * (uint64_t)sc->nF + (uint64_t)f) * (uint64_t)spt;
+    for (int s = 0; s < spt; ++s) {
+        float S, T;
+        geo_nc_t g;
+        nlos_oracle_sample(op->seed, kbase + (uint64_t)s, &S, &T);
+        if (!accept_sample_nc(&t, b, sc, f, op->accel, S, T, lb, ub, &g)) continue;
+        float ffa = emax0(-dot3(g.n, g.dirA) * dot3(t.on, g.dirA) / g.d1 / g.d1);
+        float ffb = emax0(-dot3(g.n, g.dirB) * dot3(bn, g.dirB) / g.d2 / g.d2);
+        int bin = (int)floorf(((g.d1 + g.d2) - lb) / res);
+        if (bin < 0 || bin >= nbins) continue;
+        float val = t.area * g.alb * ffa * ffb;
+        row[bin] += (double)val / (double)spt;
+    }
+}
+
+static void grad_vectors_nc(const task_t *t, v3 bn, const geo_nc_t *g, int normal_term, gvec_t *out) {
+    float c2a = dot3(t->on, g->dirA), c3a = dot3(g->n, neg3(g->dirA));
+    float c2b = dot3(bn, g->dirB), c3b = dot3(g->n, neg3(g->dirB));
+    if (c2a < 0) c2a = 0;
+    if (c3a < 0) c3a = 0;
+    if (c2b < 0) c2b = 0;
+    if (c3b < 0) c3b = 0;
+    float ffa = c2a * c3a / g->d1 / g->d1, ffb = c2b * c3b / g->d2 / g->d2;
+    v3 ia = add3(sub3(scl3(t->on, c3a), scl3(g->n, c2a)), scl3(scl3(scl3(neg3(g->dirA), 4), c2a), c3a));
+    v3 ib = add3(sub3(scl3(bn, c3b), scl3(g->n, c2b)), scl3(scl3(scl3(neg3(g->dirB), 4), c2b), c3b));
+    v3 ga = scl3(ia, 1.0f / ((g->d1 * g->d1) * g->d1));
+    v3 gb = scl3(ib, 1.0f / ((g->d2 * g->d2) * g->d2));
+    out->intensity = (double)(g->alb * ffa * ffb);
+    v3 t1 = scl3(add3(scl3(ga, ffb), scl3(gb, ffa)), g->alb);
+    v3 gn = mk(0, 0, 0);
+    if (normal_term) {
+        /* d I / d n,  I = alb c2a c3a c2b c3b / (d1^2 d2^2),  c3x = -n.dirx */
+        gn = add3(scl3(g->dirA, c3b), scl3(g->dirB, c3a));
+        gn = scl3(gn, -(g->alb * c2a * c2b));
+        gn = scl3(gn, 1.0f / ((g->d1 * g->d1) * (g->d2 * g->d2)));
+        float ct = dot3(gn, g->n);
+        gn = sub3(gn, scl3(g->n, ct));
+    }
+    v3 t2 = scl3(g->n, (float)out->intensity);
+    t2 = scl3(add3(t2, gn), 1.0f / (2 * t->area));
+    out->t1 = t1; out->t2 = t2;
+}
+
+static void gradient_task_nc(const scene_t *sc, const float *laser, const float *lnormal,
+                             const float *sensor, const float *snormal, const float *vnormal,
+                             const float *albedo, int l, int f, float lb, float ub, float res,
+                             int spt, int nbins, const double *diff_row, const taps_t *tp,
+                             int normal_term, double *grad, const nlos_oracle_opts *op) {
+    task_t t;
+    task_setup(&t, sc, laser, lnormal, l, f, vnormal, albedo);
+    if (t.degenerate) return;
+    const v3 b = ld3(sensor + 3 * (size_t)l), bn = ld3(snormal + 3 * (size_t)l);
+    uint64_t kbase = (((uint64_t)(op->source_offset + l)) * (uint64_t)sc->nF + (uint64_t)f) * (uint64_t)spt;
+    const v3 e0 = sub3(t.p2, t.p1), e1 = sub3(t.p0, t.p2), e2 = sub3(t.p1, t.p0);
+    const int vi[3] = {t.i0, t.i1, t.i2};
+    for (int s = 0; s < spt; ++s) {
+        float S, T;
+        geo_nc_t g;
+        gvec_t gv;
+        nlos_oracle_sample(op->seed, kbase + (uint64_t)s, &S, &T);
+        if (!accept_sample_nc(&t, b, sc, f, op->accel, S, T, lb, ub, &g)) continue;
+        grad_vectors_nc(&t, bn, &g, normal_term, &gv);
+        const float bw[3] = {g.u, g.v, g.w};
+        const v3 ce[3] = {cross3(gv.t2, e0), cross3(gv.t2, e1), cross3(gv.t2, e2)};
+        const v3 dsum = add3(g.dirA, g.dirB);
+        const float tot = g.d1 + g.d2;
+        for (int i = 0; i < tp->K; ++i) {
+            double delta = tap_delta(tp, i);
+            int bin = (int)floor((tot + delta - lb) / res);
+            if (bin < 0 || bin >= nbins) continue;
+            /* d(d1 + d2)/dp = dirA + dirB  (confocal: 2 dir, SMO/...:974) */
+            v3 gg = scl3(dsum, (float)(delta / tp->sigma_square));
+            v3 base = add3(gv.t1, scl3(gg, (float)gv.intensity));
+            float wk = (float)tp->w[i];
+            float dd = (float)((-2) * diff_row[bin]);
+            for (int j = 0; j < 3; ++j) {
+                v3 q = add3(scl3(base, bw[j]), ce[j]);
+                q = scl3(q, wk);
+                q = scl3(q, dd);
+                grad[3 * (size_t)vi[j] + 0] += (double)(t.area * q.x) / (double)spt;
+                grad[3 * (size_t)vi[j] + 1] += (double)(t.area * q.y) / (double)spt;
+                grad[3 * (size_t)vi[j] + 2] += (double)(t.area * q.z) / (double)spt;
+            }
+        }
+    }
+}
+
+/* P (laser, sensor) pairs; data == NULL: forward only.  Forward is always the plain histogram
+ * (refine applies to the gradient taps only, as in the v2 driver with sigma_bin < 5). */
+int nlos_oracle_render_nonconfocal(const double *data, const double *weight,
+                                   const float *laser, const float *laser_normal,
+                                   const float *sensor, const float *sensor_normal, int P,
+                                   const float *V, int nV, const float *vnormal,
+                                   const float *albedo, const int32_t *F, int nF,
+                                   int num_samples, float lb, float ub, float res,
+                                   double *transient, double *pathlengths, double *gradient,
+                                   int refine, int sigma_bin, int testing_flag, int loss_test,
+                                   const nlos_oracle_opts *opts) {
+    nlos_oracle_opts dflt;
+    if (!opts) { nlos_oracle_default_opts(&dflt); opts = &dflt; }
+    if (nF <= 0 || P < 0 || refine < 1 || sigma_bin < 1 || opts->use_ggx) return -1;
+    scene_t sc;
+    if (scene_init(&sc, V, nV, F, nF, opts->accel)) return -1;
+    const int nbins = nlos_oracle_num_bins(lb, ub, res);
+    const int spt = 1 + ((num_samples - 1) / nF);
+    if (pathlengths) fill_pathlengths(pathlengths, nbins, lb, res);
+    memset(transient, 0, sizeof(double) * (size_t)P * (size_t)nbins);
+#ifdef _OPENMP
+    if (opts->threads > 0) omp_set_num_threads(opts->threads);
+#endif
+    /* forward refinement rule of the v2 gradient driver (SMO/stratifiedStreamedGradientRenderer.cpp:521-524);
+     * forward-only calls (data == NULL) refine whenever refine > 1, like renderStreamedTransient */
+    const int fr = (data && gradient) ? (sigma_bin < 5 ? 1 : refine) : refine;
+    const int rb = nbins * fr;
+    const int Kf = 4 * fr * sigma_bin + 1;
+    double *kern = (double *)malloc(sizeof(double) * (size_t)Kf);
+    gauss_kernel(kern, fr, sigma_bin, res);
+    /* one pair per task: rows are private to the task, no reduction needed */
+#pragma omp parallel
+    {
+        double *fine = (double *)malloc(sizeof(double) * (size_t)rb);
+        double *y = (double *)malloc(sizeof(double) * (size_t)(rb + Kf - 1));
+#pragma omp for schedule(dynamic, 1)
+        for (int l = 0; l < P; ++l) {
+            double *row = transient + (size_t)l * nbins;
+            memset(fine, 0, sizeof(double) * (size_t)rb);
+            for (int f = 0; f < nF; ++f)
+                forward_task_nc(&sc, laser, laser_normal, sensor, sensor_normal, vnormal, albedo, l, f,
+                                lb, ub, res / fr, spt, rb, fine, opts);
+            if (fr <= 1) {
+                memcpy(row, fine, sizeof(double) * (size_t)nbins);
+            } else {
+                /* Gaussian + fold exactly as forward_driver() (SMO/transient_and_gradient.cpp:348-371) */
+                memset(y, 0, sizeof(double) * (size_t)(rb + Kf - 1));
+                for (int i = 0; i < rb; ++i)
+                    for (int j = 0; j < Kf; ++j) y[i + j] += fine[i] * kern[j];
+                for (int b = 0; b < rb; ++b) row[b / fr] += y[b + 2 * fr * sigma_bin];
+            }
+        }
+        free(fine); free(y);
+    }
+    free(kern);
+    if (data && gradient) {
+        size_t n = (size_t)P * (size_t)nbins;
+        double *diff = (double *)malloc(sizeof(double) * (n ? n : 1));
+        residual(data, weight, transient, n, loss_test, diff);
+        int nt = opts->normal_term < 0 ? (testing_flag == 0 && vnormal != NULL) : opts->normal_term;
+        taps_t tp;
+        taps_init(&tp, refine, sigma_bin, res);
+        int nth = 1;
+#ifdef _OPENMP
+        nth = omp_get_max_threads();
+#endif
+        double *priv = (double *)calloc((size_t)nth * 3 * (size_t)nV, sizeof(double));
+#pragma omp parallel
+        {
+            int tid = 0;
+#ifdef _OPENMP
+            tid = omp_get_thread_num();
+#endif
+            double *mine = priv + (size_t)tid * 3 * (size_t)nV;
+#pragma omp for schedule(dynamic, 64)
+            for (long long idx = 0; idx < (long long)P * nF; ++idx) {
+                int f = (int)(idx % nF), l = (int)(idx / nF);
+                gradient_task_nc(&sc, laser, laser_normal, sensor, sensor_normal, vnormal, albedo,
+                                 l, f, lb, ub, res, spt, nbins, diff + (size_t)l * nbins, &tp, nt,
+                                 mine, opts);
+            }
+        }
+        const int Ptot = opts->total_sources > 0 ? opts->total_sources : P;
+        for (int th = 0; th < nth; ++th)
+            for (size_t i = 0; i < 3 * (size_t)nV; ++i)
+                gradient[i] += priv[(size_t)th * 3 * (size_t)nV + i] / Ptot;
+        free(tp.w); free(priv); free(diff);
+    }
+    scene_free(&sc);
+    return 0;
+}
+
 /* ------------------------------------------------------------ sample tracer */
 int nlos_oracle_trace_sample(const float *origin_l, const float *normal_l,
                              int64_t l_global, int f, int s, int spt,

@@ -9,6 +9,8 @@ Reads /root/reference (read-only, absent on the GPU box) and writes DATA only:
                       /root/reference) on the cfg1 plane and on the toy mesh of
                       transient_rendering_python/test_autograd.py:35-36 -- pins the oracle's
                       closest-hit / distance / binning primitives against reference code
+  pyref_angular_nc.npz  the same prototype with lighting != sensor (row N, non-confocal pairs), incl. a
+                      blocker that hides paths from one end point only
   oracle_cfg1.npz     oracle transient + gradient for BASELINE config 1 (regression pin)
   oracle_bunny16.npz  oracle transient + gradient, bunny_5k, 16 sources (regression pin)
   ggx_table.npz       oracle GGX eval / eval_adiff / eval_nwdiff over an (alpha, n.w) grid
@@ -118,6 +120,58 @@ def make_pyref():
     np.savez_compressed(os.path.join(HERE, "pyref_angular.npz"), **out)
 
 
+def make_pyref_nc():
+    """Reference numpy prototype with lighting != sensor (non-confocal pairs), data only."""
+    sys.path.insert(0, os.path.join(REF, "transient_rendering_python"))
+    import rendering as pyref  # noqa: E402  (the reference module)
+
+    out = {}
+    rs = np.random.RandomState(11)
+    tv = np.array([[-1, -1, .9], [1, -1, 1], [1, 1, 1.2], [-1, 1, 1], [-2, -2, 1], [2, 1, 1]], np.float64)
+    tf = np.array([[0, 2, 1], [0, 3, 2], [4, 3, 0], [1, 2, 5]], np.int64)
+    # a wall-facing plane with a small blocker floating in front of it: some paths are visible from the
+    # laser but hidden from the sensor and vice versa
+    ov = np.array([[-1, -1, 1.0], [1, -1, 1.0], [1, 1, 1.0], [-1, 1, 1.0],
+                   [-.15, -.2, .55], [.25, -.1, .5], [.05, .3, .6]], np.float64)
+    of = np.array([[0, 2, 1], [0, 3, 2], [4, 6, 5]], np.int64)
+    cases = {"toy": (tv, tf), "occluder": (ov, of)}
+    pairs = [((0.1, 0, 0), (-0.3, 0.2, 0)), ((-0.4, -0.1, 0), (0.35, 0.3, 0)),
+             ((0, 0.5, 0), (0, -0.5, 0)), ((0.2, -0.3, 0), (0.2, 0.3, 0))]
+    for name, (mv, mf) in cases.items():
+        n = 512
+        d = rs.normal(size=(n, 3))
+        d[:, 2] = np.abs(d[:, 2]) + 0.4
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        mesh = types.SimpleNamespace()
+        mesh.v, mesh.f = mv, mf
+        p1, p2, p3 = mv[mf[:, 0]], mv[mf[:, 1]], mv[mf[:, 2]]
+        fn = np.cross(p2 - p1, p3 - p1)
+        fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+        mesh.fn = fn
+        opt = types.SimpleNamespace()
+        opt.sample_num = n
+        opt.max_distance_bin = 400
+        opt.distance_resolution = 0.02
+        opt.epsilon = 1e-9
+        opt.normal = "fn"
+        res = []
+        for lighting, sensor in pairs:
+            t = pyref.angular_sampling(mesh, d, np.array(lighting, np.float64), np.array(sensor, np.float64),
+                                       np.array([0, 0, 1.0]), np.array([0, 0, 1.0]), opt)
+            res.append(np.array(t))
+        out[name + "_fn"] = fn
+        out[name + "_v"] = mv
+        out[name + "_f"] = mf
+        out[name + "_dir"] = d
+        out[name + "_laser"] = np.array([p[0] for p in pairs], np.float64)
+        out[name + "_sensor"] = np.array([p[1] for p in pairs], np.float64)
+        out[name + "_nbin"] = np.int64(opt.max_distance_bin)
+        out[name + "_res"] = np.float64(opt.distance_resolution)
+        out[name + "_transient"] = np.stack(res)
+        print("pyref nc", name, np.stack(res).sum(axis=1))
+    np.savez_compressed(os.path.join(HERE, "pyref_angular_nc.npz"), **out)
+
+
 def make_oracle_cfg1():
     v, f, origin, normal = cfg1()
     lb, ub, res = 0.0, 2.0, 2.0 ** -5
@@ -169,6 +223,7 @@ if __name__ == "__main__":
         sys.exit("needs /root/reference (build container only)")
     bv, bf = make_meshes()
     make_pyref()
+    make_pyref_nc()
     make_oracle_cfg1()
     make_oracle_bunny(bv, bf)
     make_ggx_table()
