@@ -117,6 +117,22 @@ int nlos_v1_streamed_render_transient(float *origin, int numSources, float *norm
         int *triangles, int numTriangles, int numSamples, float lowerBound,
         float upperBound, float resolution, double *transient, double *pathlengths);
 
+/* Non-confocal (laser, sensor) pairs -- SURVEY.md 8a row N.  No native reference function exists
+ * (prototypes: transient_rendering_python/rendering.py:8-93, mesh_optimization/rendering.py:739-797);
+ * the parameter lists extend streamed_render_transient / streamed_render_gradient by the sensor
+ * arrays.  Pair i = (laser[i], sensor[i]).  gradient is accumulated into (v2 semantics). */
+int nlos_nonconfocal_render_transient(float *laser, float *laserNormal, float *sensor,
+        float *sensorNormal, int numPairs, float *vertices, int numVertices,
+        float *vertexNormal, float *vertexAlbedo, int *triangles, int numTriangles,
+        int numSamples, float lowerBound, float upperBound, float resolution,
+        double *transient, double *pathlengths, int refine_scale, int sigma_bin);
+int nlos_nonconfocal_render_gradient(double *data, double *weight, float *laser,
+        float *laserNormal, float *sensor, float *sensorNormal, int numPairs,
+        float *vertices, int numVertices, float *vertexNormal, float *vertexAlbedo,
+        int *triangles, int numTriangles, int numSamples, float lowerBound, float upperBound,
+        float resolution, double *transient, double *pathlengths, double *gradient,
+        int refine_scale, int sigma_bin, int testing_flag, int loss_test);
+
 /* embree_intersector/c_embree_intersector.h:3-9 */
 int nlos_embree3_tbb_line_intersection(float *origins, float *directions, int num_ray,
         float *vertices, int num_vertices, int *triangles, int num_triangles,
@@ -202,6 +218,15 @@ typedef struct nlos_render_args {
                                    previous render on this ctx (same mesh, sources, samples, seed) */
     int32_t force_bvh;          /* 1: occlusion by BVH traversal only (default 0: per-source perspective
                                    grid in LDS when the mesh fits, BVH otherwise; identical results) */
+    /* non-confocal pairs (the reference has only Python prototypes of it:
+     * transient_rendering_python/rendering.py:8-93, mesh_optimization/rendering.py:739-797).
+     * NULL = confocal.  Otherwise measurement l is the pair (laser origin[l], sensor[l]): the
+     * surface point must be the closest hit seen from BOTH wall points, the path length is
+     * d1 + d2, the form factor is the product of the two legs' clamped form factors; v2
+     * conventions otherwise, so sensor == origin reproduces the confocal rows.  TRANSIENT and
+     * GRADIENT modes, Lambertian only. */
+    const float *sensor;        /* [L,3] or NULL */
+    const float *sensor_normal; /* [L,3] (required with sensor) */
 } nlos_render_args;
 
 int  nlos_sizeof_render_args(void);                 /* for FFI layout checks */

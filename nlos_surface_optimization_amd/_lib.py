@@ -64,6 +64,8 @@ class RenderArgs(ctypes.Structure):
         ("keep_visibility", ctypes.c_int32),
         ("reuse_visibility", ctypes.c_int32),
         ("force_bvh", ctypes.c_int32),
+        ("sensor", ctypes.c_void_p),
+        ("sensor_normal", ctypes.c_void_p),
     ]
 
 
@@ -93,6 +95,8 @@ SYMBOLS = {
     "nlos_ggx_streamed_render_gradient_alpha": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _F, _I, _F, _F, _F, _P, _P, _I, _I, _P]),
     "nlos_v1_streamed_render_gradient": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _I, _P, _P, _P]),
     "nlos_v1_streamed_render_transient": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P]),
+    "nlos_nonconfocal_render_transient": (_I, [_P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _I, _I]),
+    "nlos_nonconfocal_render_gradient": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _I, _I, _I, _I]),
     "nlos_embree3_tbb_line_intersection": (_I, [_P, _P, _I, _P, _I, _P, _I, _P]),
     "nlos_embree3_tbb_short_line_intersection": (_I, [_P, _P, _I, _P, _I, _P, _I, _P]),
     "nlos_barycentric_to_world_n": (_I, [_P, _I, _P, _I, _P, _I, _P]),

@@ -82,7 +82,7 @@ struct nlos_ctx {
     DevBuf vis, diff, fine, taps, rows_tmp, grad_tmp, live;
     int tap_refine = -1, tap_sigma = -1; float tap_res = -1.0f; int tap_kind = -1;
     // host-pointer path staging
-    DevBuf io[12];
+    DevBuf io[16];
     // what the visibility cache currently describes
     struct VisKey { int L = -1, F = -1, V = -1, spt = -1; long long off = -1; uint64_t seed = 0; float lb = 0, ub = 0;
                     int feat = -1; } vis_key;
@@ -383,6 +383,12 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     if (mode < 0 || mode > NLOS_MODE_GRADIENT_V1) return fail(NLOS_ERR_ARG, "nlos_render: unknown mode");
     if (mode == NLOS_MODE_VERTEX_GRADIENT && (a->vertex_num < 0 || a->vertex_num >= a->V))
         return fail(NLOS_ERR_ARG, "nlos_render: vertex_num out of range");
+    if (a->sensor) {
+        if (!a->sensor_normal) return fail(NLOS_ERR_ARG, "nlos_render: sensor needs sensor_normal");
+        if (mode != NLOS_MODE_TRANSIENT && mode != NLOS_MODE_GRADIENT)
+            return fail(NLOS_ERR_ARG, "nlos_render: non-confocal pairs support TRANSIENT and GRADIENT modes only");
+        if (a->use_ggx || !a->clamp) return fail(NLOS_ERR_ARG, "nlos_render: non-confocal pairs are Lambertian with clamped form factors");
+    }
 
     DeviceGuard guard(c->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -401,6 +407,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     nlos::SourceView src;
     src.origin = a->origin; src.normal = a->normal; src.L = L;
     src.source_offset = a->source_offset; src.total_sources = a->total_sources;
+    src.sensor = a->sensor; src.sensor_normal = a->sensor ? a->sensor_normal : nullptr;
 
     nlos::SampleParams sp;
     sp.seed = a->seed; sp.spt = spt; sp.lb = lb; sp.ub = ub;
@@ -444,7 +451,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     nlos_ctx::VisKey key;
     key.L = L; key.F = nF; key.V = nV; key.spt = spt; key.off = a->source_offset; key.seed = a->seed;
     key.lb = lb; key.ub = ub;
-    key.feat = (vn ? 1 : 0) | (alb ? 2 : 0) | (sp.use_ggx ? 4 : 0) | (sp.clamp ? 8 : 0);
+    key.feat = (vn ? 1 : 0) | (alb ? 2 : 0) | (sp.use_ggx ? 4 : 0) | (sp.clamp ? 8 : 0) | (a->sensor ? 16 : 0);
     const bool skip_pass1 = a->reuse_visibility != 0;
     if (skip_pass1) {
         const nlos_ctx::VisKey& k = c->vis_key;
@@ -666,6 +673,7 @@ struct HostRender {
     int mode = NLOS_MODE_TRANSIENT;
     double *data = nullptr, *weight = nullptr;
     float *origin = nullptr, *normal = nullptr, *vertices = nullptr, *vnormal = nullptr, *albedo = nullptr;
+    float *sensor = nullptr, *sensor_normal = nullptr;
     int* faces = nullptr;
     int L = 0, V = 0, F = 0, num_samples = 0;
     float lb = 0, ub = 0, res = 1;
@@ -692,6 +700,8 @@ int host_render(const HostRender& h) {
     a.mode = h.mode;
     a.origin = hc.up(h.origin, 3 * (size_t)h.L);
     a.normal = hc.up(h.normal, 3 * (size_t)h.L);
+    a.sensor = hc.up(h.sensor, 3 * (size_t)h.L);
+    a.sensor_normal = hc.up(h.sensor_normal, 3 * (size_t)h.L);
     a.L = h.L; a.source_offset = 0; a.total_sources = h.L;
     a.vertices = hc.up(h.vertices, 3 * (size_t)h.V); a.V = h.V;
     a.faces = hc.up(h.faces, 3 * (size_t)h.F); a.F = h.F;
@@ -738,6 +748,41 @@ int nlos_streamed_render_transient(float* origin, int numSources, float* normal,
     h.vnormal = vertexNormal; h.albedo = vertexAlbedo; h.faces = triangles; h.F = numTriangles;
     h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
     h.transient = transient; h.pathlengths = pathlengths; h.refine = refine_scale; h.sigma_bin = sigma_bin;
+    return host_render(h);
+}
+
+int nlos_nonconfocal_render_transient(float* laser, float* laserNormal, float* sensor, float* sensorNormal,
+                                      int numPairs, float* vertices, int numVertices, float* vertexNormal,
+                                      float* vertexAlbedo, int* triangles, int numTriangles, int numSamples,
+                                      float lowerBound, float upperBound, float resolution, double* transient,
+                                      double* pathlengths, int refine_scale, int sigma_bin) {
+    if (numPairs > 0 && (!sensor || !sensorNormal)) return fail(NLOS_ERR_ARG, "non-confocal render: sensor arrays are NULL");
+    HostRender h;
+    h.mode = NLOS_MODE_TRANSIENT;
+    h.origin = laser; h.normal = laserNormal; h.sensor = sensor; h.sensor_normal = sensorNormal; h.L = numPairs;
+    h.vertices = vertices; h.V = numVertices;
+    h.vnormal = vertexNormal; h.albedo = vertexAlbedo; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.transient = transient; h.pathlengths = pathlengths; h.refine = refine_scale; h.sigma_bin = sigma_bin;
+    return host_render(h);
+}
+
+int nlos_nonconfocal_render_gradient(double* data, double* weight, float* laser, float* laserNormal, float* sensor,
+                                     float* sensorNormal, int numPairs, float* vertices, int numVertices,
+                                     float* vertexNormal, float* vertexAlbedo, int* triangles, int numTriangles,
+                                     int numSamples, float lowerBound, float upperBound, float resolution,
+                                     double* transient, double* pathlengths, double* gradient, int refine_scale,
+                                     int sigma_bin, int testing_flag, int loss_test) {
+    if (numPairs > 0 && (!sensor || !sensorNormal)) return fail(NLOS_ERR_ARG, "non-confocal render: sensor arrays are NULL");
+    HostRender h;
+    h.mode = NLOS_MODE_GRADIENT;
+    h.data = data; h.weight = weight;
+    h.origin = laser; h.normal = laserNormal; h.sensor = sensor; h.sensor_normal = sensorNormal; h.L = numPairs;
+    h.vertices = vertices; h.V = numVertices;
+    h.vnormal = vertexNormal; h.albedo = vertexAlbedo; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.transient = transient; h.pathlengths = pathlengths; h.gradient = gradient;
+    h.refine = refine_scale; h.sigma_bin = sigma_bin; h.testing_flag = testing_flag; h.loss_test = loss_test;
     return host_render(h);
 }
 

@@ -46,6 +46,9 @@ struct SourceView {
     int L;
     long long source_offset; // global index of origin[0]
     int total_sources;       // for 1/L
+    // row N (non-confocal pairs): sensor point / wall normal of pair l; null = confocal
+    const float* sensor;     // [L,3] or null
+    const float* sensor_normal;  // [L,3] or null
 };
 
 struct SampleParams {

@@ -303,6 +303,167 @@ __global__ __launch_bounds__(256) void k_forward(ForwardArgs a, int rows_in_lds)
     }
 }
 
+// ------------------------------------------------------- forward, row N (pairs)
+// Non-confocal pair l = (laser a, sensor b).  No native reference kernel exists;
+// geometry follows the reference prototypes (transient_rendering_python/rendering.py:37-93: nearest
+// hit from the laser, second segment visible from the sensor, path d1 + d2) with the v2
+// conventions of rows F/G, so a == b gives the confocal rows bit for bit.
+struct GeoNC {
+    float u, v, w, d1, d2;
+    V3 dirA, dirB, n;
+    float alb;
+};
+
+template <int FEAT>
+__device__ __forceinline__ bool sample_geo_nc(const Face& f, const Tri& tr, V3 oa, V3 ob, uint64_t seed, uint64_t k,
+                                              float lb, float ub, const float* __restrict__ vn,
+                                              const float* __restrict__ alb, GeoNC& g, float& tA, float& tB) {
+    float S, T;
+    sample_st(seed, k, S, T);
+    float sq = sqrtf(T);
+    float u = 1 - sq;
+    float v = (1 - S) * sq;
+    float w = S * sq;
+    V3 p = bary(u, f.p0, v, f.p1, w, f.p2);
+    V3 dA = p - oa;
+    g.dirA = dA * (1.0f / sqrtf(dot(dA, dA)));
+    float hu, hv;
+    if (!tri_test(tr, oa, g.dirA, tA, hu, hv)) return false;
+    g.v = hu;
+    g.w = hv;
+    g.u = 1.0f - g.v - g.w;
+    V3 qA = bary(g.u, f.p0, g.v, f.p1, g.w, f.p2);
+    V3 eA = qA - oa;
+    g.d1 = sqrtf(dot(eA, eA));
+    V3 dB = p - ob;
+    g.dirB = dB * (1.0f / sqrtf(dot(dB, dB)));
+    float bu, bv;
+    if (!tri_test(tr, ob, g.dirB, tB, bu, bv)) return false;
+    V3 qB = bary(1.0f - bu - bv, f.p0, bu, f.p1, bv, f.p2);
+    V3 eB = qB - ob;
+    g.d2 = sqrtf(dot(eB, eB));
+    const float tot = g.d1 + g.d2;
+    if (!((tot <= ub) && (tot >= lb))) return false;
+    g.n = f.fn;
+    if (FEAT & FEAT_VN) {
+        g.n = bary(g.u, ld3(vn + 3 * (size_t)f.i0), g.v, ld3(vn + 3 * (size_t)f.i1), g.w,
+                   ld3(vn + 3 * (size_t)f.i2));
+    }
+    g.alb = 1.0f;
+    if (FEAT & FEAT_ALB) g.alb = g.u * alb[f.i0] + g.v * alb[f.i1] + g.w * alb[f.i2];
+    return true;
+}
+
+// one leg of a chunk: packet traversal when every live ray is z-major, per-ray traversal otherwise
+template <int CH>
+__device__ __forceinline__ uint32_t trace_leg(const SceneView& sc, V3 o, const float (&dx)[CH], const float (&dy)[CH],
+                                              const float (&dz)[CH], const float (&ts)[CH], uint32_t alive,
+                                              bool zmajor, int self, int self_fid) {
+    if (!alive) return 0u;
+    if (zmajor) return trace_packet<CH>(sc.nodes, sc.n_nodes, sc.tris, sc.face_id, o, dx, dy, dz, ts, alive, self, self_fid);
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+        if ((alive & (1u << c)) &&
+            occluded(sc.nodes, sc.n_nodes, sc.tris, sc.face_id, o, mk(dx[c], dy[c], dz[c]), ts[c], self, self_fid))
+            alive &= ~(1u << c);
+    return alive;
+}
+
+template <int FEAT, int CH>
+__global__ __launch_bounds__(256) void k_forward_nc(ForwardArgs a, int rows_in_lds) {
+    extern __shared__ double s_lds[];       // [ticket (8 B)][histogram row]
+    int* s_next = reinterpret_cast<int*>(s_lds);
+    double* s_row = s_lds + 1;
+
+    const int l = blockIdx.x;
+    const int nbins = a.sp.nbins;
+    const int F = a.sc.F;
+    if (rows_in_lds)
+        for (int i = threadIdx.x; i < nbins; i += blockDim.x) s_row[i] = 0.0;
+    if (threadIdx.x == 0) *s_next = 0;
+    __syncthreads();
+
+    const V3 oa = ld3(a.src.origin + 3 * (size_t)l), na = ld3(a.src.normal + 3 * (size_t)l);
+    const V3 ob = ld3(a.src.sensor + 3 * (size_t)l), nb = ld3(a.src.sensor_normal + 3 * (size_t)l);
+    const uint64_t lg = (uint64_t)(a.src.source_offset + l);
+    const int spt = a.sp.spt;
+    const float lb = a.sp.lb, ub = a.sp.ub, res = a.sp.res;
+    double* grow = a.rows + (size_t)l * nbins;
+    const int nblocks = (F + 63) >> 6;
+    const int lane = threadIdx.x & 63;
+
+    for (;;) {
+        const int b = wave_ticket(s_next);
+        if (b >= nblocks) break;
+        const int j = (b << 6) + lane;
+        if (j >= F) continue;
+        const Face f = load_face(a.sc.facerec, j);
+        uint32_t* visp = a.vis ? a.vis + ((size_t)l * a.vis_words) * F + j : nullptr;
+        if (f.degenerate) {
+            if (visp)
+                for (int wi = 0; wi < a.vis_words; ++wi) visp[(size_t)wi * F] = 0u;
+            continue;
+        }
+        const Tri tr = load_tri(a.sc.tris, j);
+        const uint64_t kbase = (lg * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
+        uint32_t word = 0;
+        for (int c0 = 0; c0 < spt; c0 += CH) {
+            float ax[CH], ay[CH], az[CH], ta[CH], bx[CH], by[CH], bz[CH], tb[CH], val[CH];
+            int bin[CH];
+            uint32_t alive = 0;
+            bool zmA = true, zmB = true;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int s = c0 + c;
+                GeoNC g;
+                float tA = 0.0f, tB = 0.0f;
+                bool ok = s < spt;
+                if (ok)
+                    ok = sample_geo_nc<FEAT>(f, tr, oa, ob, a.sp.seed, kbase + (uint64_t)s, lb, ub, a.sc.vertex_normal,
+                                             a.sc.albedo, g, tA, tB);
+                float vv = 0.0f;
+                int bb = -1;
+                if (ok) {
+                    const float ffa = emax0(-dot(g.n, g.dirA) * dot(na, g.dirA) / g.d1 / g.d1);
+                    const float ffb = emax0(-dot(g.n, g.dirB) * dot(nb, g.dirB) / g.d2 / g.d2);
+                    ok = ffa > 0.0f && ffb > 0.0f;      // zero contribution in both passes: never trace
+                    vv = f.area * g.alb * ffa * ffb;
+                    bb = (int)floorf(((g.d1 + g.d2) - lb) / res);
+                }
+                ax[c] = ok ? g.dirA.x : 0.0f; ay[c] = ok ? g.dirA.y : 0.0f; az[c] = ok ? g.dirA.z : 1.0f;
+                bx[c] = ok ? g.dirB.x : 0.0f; by[c] = ok ? g.dirB.y : 0.0f; bz[c] = ok ? g.dirB.z : 1.0f;
+                ta[c] = tA; tb[c] = tB;
+                val[c] = vv;
+                bin[c] = bb;
+                if (ok) {
+                    alive |= 1u << c;
+                    zmA = zmA && (g.dirA.z >= 0.05f);
+                    zmB = zmB && (g.dirB.z >= 0.05f);
+                }
+            }
+            alive = trace_leg<CH>(a.sc, oa, ax, ay, az, ta, alive, zmA, j, f.fid);
+            alive = trace_leg<CH>(a.sc, ob, bx, by, bz, tb, alive, zmB, j, f.fid);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if ((alive & (1u << c)) && bin[c] >= 0 && bin[c] < nbins) {
+                    double cc = (double)val[c] / (double)spt;
+                    if (rows_in_lds) unsafeAtomicAdd(&s_row[bin[c]], cc);
+                    else unsafeAtomicAdd(&grow[bin[c]], cc);
+                }
+            }
+            word |= alive << (c0 & 31);
+            if (((c0 + CH) & 31) == 0 || c0 + CH >= spt) {
+                if (visp) visp[(size_t)(c0 >> 5) * F] = word;
+                word = 0;
+            }
+        }
+    }
+    if (rows_in_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nbins; i += blockDim.x) grow[i] = s_row[i];
+    }
+}
+
 // ------------------------------------------------------------- forward (grid)
 // Per-source perspective grid.  Every ray of a workgroup starts at the same wall point o, so the
 // triangles that can block the ray towards slope (mx, my) = (dx/dz, dy/dz) are exactly those whose
@@ -905,6 +1066,35 @@ __device__ __forceinline__ void grad_vectors(const Face& f, const Geo& g, V3 on,
     out.t2 = t2;
 }
 
+// Row N: t1 = alb (ff_b grad ff_a + ff_a grad ff_b), grad ff = (n_o c3 - n c2 - 4 dir c2 c3) / d^3;
+// normal term dI/dn projected as in the confocal rows
+template <int FEAT>
+__device__ __forceinline__ void grad_vectors_nc(const Face& f, const GeoNC& g, V3 na, V3 nb, int normal_term, GVec& out) {
+    float c2a = dot(na, g.dirA), c3a = dot(g.n, -g.dirA);
+    float c2b = dot(nb, g.dirB), c3b = dot(g.n, -g.dirB);
+    if (c2a < 0) c2a = 0;
+    if (c3a < 0) c3a = 0;
+    if (c2b < 0) c2b = 0;
+    if (c3b < 0) c3b = 0;
+    const float ffa = c2a * c3a / g.d1 / g.d1, ffb = c2b * c3b / g.d2 / g.d2;
+    const V3 ia = ((na * c3a) - (g.n * c2a)) + ((((-g.dirA) * 4.0f) * c2a) * c3a);
+    const V3 ib = ((nb * c3b) - (g.n * c2b)) + ((((-g.dirB) * 4.0f) * c2b) * c3b);
+    const V3 ga = ia * (1.0f / ((g.d1 * g.d1) * g.d1));
+    const V3 gb = ib * (1.0f / ((g.d2 * g.d2) * g.d2));
+    out.inten_f = g.alb * ffa * ffb;
+    out.t1 = ((ga * ffb) + (gb * ffa)) * g.alb;
+    V3 gn = mk(0, 0, 0);
+    if (normal_term) {
+        gn = (g.dirA * c3b) + (g.dirB * c3a);
+        gn = gn * (-(g.alb * c2a * c2b));
+        gn = gn * (1.0f / ((g.d1 * g.d1) * (g.d2 * g.d2)));
+        float ct = dot(gn, g.n);
+        gn = gn - g.n * ct;
+    }
+    V3 t2 = g.n * out.inten_f;
+    out.t2 = (t2 + gn) * (1.0f / (2 * f.area));
+}
+
 // bin of tap i: floor((2h + delta_i - lb) / res) in double
 // (smoothed_transient/transient_and_gradient.cpp:975-976); reciprocal multiply with an
 // exact-division fallback when the quotient is within 1e-9 of an integer.
@@ -962,7 +1152,7 @@ __device__ __forceinline__ void grouped_taps(const TapTables& tt, const double* 
 // MODE 0: per-vertex gradient [V,3]; 1: scalar d/d albedo; 2: scalar d/d alpha (GGX);
 //      3: single-vertex per-bin gradient [T,3]
 // two 512-thread workgroups per CU (LDS: ~76 KB each) need <= 128 VGPRs
-template <int FEAT, int MODE>
+template <int FEAT, int MODE, bool NC = false>
 __global__ __launch_bounds__(512, 4) void k_gradient(GradientArgs a) {
     extern __shared__ double s_mem[];       // [ticket (8 B)][diff row T][tap tables 3K+2][grad 3V][masks][bases][live]
     int* s_next = reinterpret_cast<int*>(s_mem);
@@ -1033,6 +1223,8 @@ __global__ __launch_bounds__(512, 4) void k_gradient(GradientArgs a) {
         const int live_blocks = (n_live + 63) >> 6;
         const V3 o = ld3(a.src.origin + 3 * (size_t)l);
         const V3 on = ld3(a.src.normal + 3 * (size_t)l);
+        const V3 ob = NC ? ld3(a.src.sensor + 3 * (size_t)l) : o;
+        const V3 onb = NC ? ld3(a.src.sensor_normal + 3 * (size_t)l) : on;
         const uint64_t lg = (uint64_t)(a.src.source_offset + l);
 
         for (;;) {
@@ -1057,6 +1249,31 @@ __global__ __launch_bounds__(512, 4) void k_gradient(GradientArgs a) {
                     const int bit = __ffs(word) - 1;
                     word &= word - 1;
                     const int s = (wi << 5) + bit;
+                    if (NC) {
+                        // row N: two legs, d(d1 + d2)/dp = dirA + dirB; P1 carries the confocal factor 2
+                        GeoNC gc;
+                        float tA, tB;
+                        if (!sample_geo_nc<FEAT>(f, tr, o, ob, a.sp.seed, kbase + (uint64_t)s, a.sp.lb, a.sp.ub,
+                                                 a.sc.vertex_normal, a.sc.albedo, gc, tA, tB))
+                            continue;
+                        GVec gv;
+                        grad_vectors_nc<FEAT>(f, gc, on, onb, a.normal_term, gv);
+                        const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
+                        const V3 ce[3] = {cross(gv.t2, e0), cross(gv.t2, e1), cross(gv.t2, e2)};
+                        double s0, s1;
+                        grouped_taps(tt, s_diff, T, (double)(gc.d1 + gc.d2), lbd, resd, inv_res, s0, s1);
+                        const V3 di = ((gc.dirA + gc.dirB) * 0.5f) * gv.inten_f;
+                        const float bw[3] = {gc.u, gc.v, gc.w};
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            V3 A1 = gv.t1 * bw[q] + ce[q];
+                            V3 A2 = di * bw[q];
+                            acc[3 * q + 0] += (double)A1.x * s0 + (double)A2.x * s1;
+                            acc[3 * q + 1] += (double)A1.y * s0 + (double)A2.y * s1;
+                            acc[3 * q + 2] += (double)A1.z * s0 + (double)A2.z * s1;
+                        }
+                        continue;
+                    }
                     Geo g;
                     float t_self;
                     if (!sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, a.sp.lb, a.sp.ub,
@@ -1215,6 +1432,12 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
 
 template <int FEAT>
 void forward_launch(const ForwardArgs& a, int rows_in_lds, size_t lds, hipStream_t stream) {
+    if (a.src.sensor) {
+        // row N: two shadow legs per sample through the BVH (the per-source grid serves one origin)
+        if constexpr ((FEAT & FEAT_GGX) == 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_nc<FEAT, 4>), dim3(a.src.L), dim3(256), lds, stream, a, rows_in_lds);
+        return;
+    }
     if (forward_grid_launch<FEAT>(a, rows_in_lds, stream)) return;
     // chunk = rays traced together per (source, face): 4 when spt <= 4, else 8
     if (a.sp.spt <= 4)
@@ -1232,6 +1455,14 @@ void gradient_launch2(const GradientArgs& a, int grid, size_t lds, hipStream_t s
 
 template <int FEAT>
 void gradient_launch(const GradientArgs& a, int grid, size_t lds, hipStream_t stream) {
+    if (a.src.sensor) {
+        if constexpr ((FEAT & FEAT_GGX) == 0) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, 0, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, 0, true>), dim3(grid), dim3(512), lds, stream, a);
+        }
+        return;
+    }
     switch (a.mode) {
         case 0: gradient_launch2<FEAT, 0>(a, grid, lds, stream); break;
         case 1: gradient_launch2<FEAT, 1>(a, grid, lds, stream); break;

@@ -92,7 +92,8 @@ class TransientRenderer:
 
     def _args(self, mode, origin, normal, vertices, faces, num_sample, lower_bound, upper_bound,
               resolution, refine_scale=1, sigma_bin=1, vertex_normal=None, albedo=None,
-              source_offset=0, total_sources=0, alpha=None, seed=None, force_bvh=False):
+              source_offset=0, total_sources=0, alpha=None, seed=None, force_bvh=False,
+              sensor=None, sensor_normal=None):
         a = _lib.RenderArgs()
         self._lib.nlos_render_args_init(ctypes.byref(a))
         _want(origin, torch.float32, "origin", 2); _want(normal, torch.float32, "normal", 2)
@@ -114,6 +115,13 @@ class TransientRenderer:
         if alpha is not None:
             a.use_ggx, a.ggx_alpha = 1, float(alpha)
         a.force_bvh = 1 if force_bvh else 0
+        if sensor is not None:
+            # row N: measurement l is the pair (laser origin[l], sensor[l]); default sensor wall normal = laser's
+            if sensor_normal is None:
+                sensor_normal = normal
+            _want(sensor, torch.float32, "sensor", 2); _want(sensor_normal, torch.float32, "sensor_normal", 2)
+            assert sensor.shape == origin.shape and sensor_normal.shape == origin.shape, "sensor/sensor_normal need to be Lx3"
+            a.sensor, a.sensor_normal = _dptr(sensor), _dptr(sensor_normal)
         return a
 
     def _run(self, a, keep):

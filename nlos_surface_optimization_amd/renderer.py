@@ -205,3 +205,59 @@ def renderStreamedVertexGradient(origin, normal, vertices, faces, num_sample, lo
         faces.shape[0], int(num_sample), lower_bound, upper_bound, resolution, ptr(gradient),
         int(refine_scale), int(sigma_bin))
     _lib.check(rc, "streamed_render_vertex_gradient")
+
+
+# ---------------------------------------------------------------------------------------------
+# Row N: non-confocal (laser, sensor) pairs.  The reference has no native
+# function for it (prototypes only: transient_rendering_python/rendering.py:8-93,
+# mesh_optimization/rendering.py:739-797); these two follow renderStreamedTransient /
+# renderStreamedGradient with the sensor arrays inserted after the laser's.
+def _pairs(laser, laser_normal, sensor, sensor_normal, vertices, faces):
+    L = _common(laser, laser_normal, vertices, faces)
+    f32(sensor, 2, "sensor"); f32(sensor_normal, 2, "sensor_normal")
+    assert sensor.shape[0] == L and sensor.shape[1] == 3, "sensor needs to be Lx3"
+    assert sensor_normal.shape[0] == L and sensor_normal.shape[1] == 3, "sensor normal needs to be Lx3"
+    return L
+
+
+def renderNonConfocalTransient(laser, laser_normal, sensor, sensor_normal, vertices, faces, num_sample,
+                               lower_bound, upper_bound, resolution, transient, pathlengths,
+                               refine_scale=1, sigma_bin=1, vertexNormal=None, albedo=None):
+    """transient[i] = three-bounce histogram of pair (laser[i], sensor[i]); bins floor((d1+d2-lb)/res)."""
+    L = _pairs(laser, laser_normal, sensor, sensor_normal, vertices, faces)
+    _check_tp(transient, pathlengths, L, _num_bins(lower_bound, upper_bound, resolution))
+    if vertexNormal is not None:
+        f32(vertexNormal, 2, "vertexNormal")
+        assert vertexNormal.shape == vertices.shape, "vertex normal needs to be Vx3"
+    if albedo is not None:
+        f32(albedo, 1, "albedo")
+        assert vertices.shape[0] == albedo.shape[0], "albedo nees to be Vx1"
+    rc = _lib.lib().nlos_nonconfocal_render_transient(
+        ptr(laser), ptr(laser_normal), ptr(sensor), ptr(sensor_normal), L, ptr(vertices), vertices.shape[0],
+        ptr(vertexNormal), ptr(albedo), ptr(faces), faces.shape[0], int(num_sample), lower_bound, upper_bound,
+        resolution, ptr(transient), ptr(pathlengths), int(refine_scale), int(sigma_bin))
+    _lib.check(rc, "nonconfocal_render_transient")
+
+
+def renderNonConfocalGradient(laser, laser_normal, sensor, sensor_normal, vertices, faces, num_sample,
+                              lower_bound, upper_bound, resolution, transient, pathlengths, gradient, data,
+                              weight, refine_scale, sigma_bin, testing_flag, loss_flag, vertexNormal=None,
+                              albedo=None):
+    """Vertex gradient of sum w (data - T)^2 / L over the pairs; accumulated into `gradient` (v2 semantics)."""
+    L = _pairs(laser, laser_normal, sensor, sensor_normal, vertices, faces)
+    numBins = _num_bins(lower_bound, upper_bound, resolution)
+    _check_tp(transient, pathlengths, L, numBins)
+    _check_dw(data, weight, L, numBins)
+    _check_grad(gradient, vertices)
+    if vertexNormal is not None:
+        f32(vertexNormal, 2, "vertexNormal")
+        assert vertexNormal.shape == vertices.shape, "vertex normal needs to be Vx3"
+    if albedo is not None:
+        f32(albedo, 1, "albedo")
+        assert vertices.shape[0] == albedo.shape[0], "albedo nees to be Vx1"
+    rc = _lib.lib().nlos_nonconfocal_render_gradient(
+        ptr(data), ptr(weight), ptr(laser), ptr(laser_normal), ptr(sensor), ptr(sensor_normal), L, ptr(vertices),
+        vertices.shape[0], ptr(vertexNormal), ptr(albedo), ptr(faces), faces.shape[0], int(num_sample),
+        lower_bound, upper_bound, resolution, ptr(transient), ptr(pathlengths), ptr(gradient),
+        int(refine_scale), int(sigma_bin), int(testing_flag), int(loss_flag))
+    _lib.check(rc, "nonconfocal_render_gradient")

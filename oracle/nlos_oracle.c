@@ -1185,6 +1185,10 @@ static void gradient_task_nc(const scene_t *sc, const float *laser, const float 
         gvec_t gv;
         nlos_oracle_sample(op->seed, kbase + (uint64_t)s, &S, &T);
         if (!accept_sample_nc(&t, b, sc, f, op->accel, S, T, lb, ub, &g)) continue;
+        /* a leg whose clamped form factor is zero contributes nothing (d max(0,x)/dx = 0 there;
+         * the confocal expressions vanish by themselves through their c2*c3 factor) */
+        if (!(emax0(-dot3(g.n, g.dirA) * dot3(t.on, g.dirA) / g.d1 / g.d1) > 0.0f)) continue;
+        if (!(emax0(-dot3(g.n, g.dirB) * dot3(bn, g.dirB) / g.d2 / g.d2) > 0.0f)) continue;
         grad_vectors_nc(&t, bn, &g, normal_term, &gv);
         const float bw[3] = {g.u, g.v, g.w};
         const v3 ce[3] = {cross3(gv.t2, e0), cross3(gv.t2, e1), cross3(gv.t2, e2)};

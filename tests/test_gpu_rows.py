@@ -334,3 +334,71 @@ def test_large_mesh_uses_bvh_path_vs_oracle(orc):
     renderer.renderStreamedTransient(origin, normal, v2, f2, 30000, LB, UB, RES, tr, path, 1, 1)
     t_o, _ = orc.render_transient(origin, normal, v2, f2, 30000, LB, UB, RES, accel=1)
     assert rel_l2(tr, t_o) <= 1e-5 and tr.sum() > 0
+
+
+# ------------------------------------------------------------------ row N: non-confocal pairs
+def _nc_pairs(n=3):
+    a, na = grid_sources(n, 0.2)
+    b = a.copy()
+    rs = np.random.RandomState(9)
+    b[:, :2] += rs.uniform(-0.15, 0.15, (a.shape[0], 2)).astype(np.float32)
+    return a, na, np.ascontiguousarray(b), na.copy()
+
+
+@pytest.mark.parametrize("variant", ["plain", "shading_gn", "albedo", "sigma5"])
+def test_nonconfocal_pairs_vs_oracle(bunny, orc, variant):
+    """Row N through the host-pointer C ABI: transient and vertex gradient of (laser, sensor) pairs."""
+    from nlos_surface_optimization_amd import renderer
+    v, f = bunny
+    a, na, b, nb = _nc_pairs()
+    ns = 20000
+    vn = vertex_normals(v, f) if variant == "shading_gn" else None
+    alb = None
+    if variant == "albedo":
+        alb = (0.3 + 0.7 * np.random.RandomState(4).random_sample(v.shape[0])).astype(np.float32)
+    refine, sb, tf = (4, 5, 1) if variant == "sigma5" else (10, 1, 0 if variant == "shading_gn" else 1)
+    t0, _, _ = orc.render_nonconfocal(a, na, b, nb, v, f, ns, LB, UB, RES, vnormal=vn, albedo=alb, accel=1,
+                                      refine=1)
+    rs = np.random.RandomState(6)
+    data = t0 * (1 + 0.3 * rs.standard_normal(t0.shape))
+    w = 0.5 + rs.random_sample(t0.shape)
+    t_ref, g_ref, p_ref = orc.render_nonconfocal(a, na, b, nb, v, f, ns, LB, UB, RES, data=data, weight=w,
+                                                 refine=refine, sigma_bin=sb, testing_flag=tf, vnormal=vn,
+                                                 albedo=alb, accel=1)
+    L = a.shape[0]
+    tr, path, grad = np.zeros((L, T)), np.zeros(T), np.zeros((v.shape[0], 3))
+    renderer.renderNonConfocalGradient(a, na, b, nb, v, f, ns, LB, UB, RES, tr, path, grad, data, w, refine, sb,
+                                       tf, 0, vertexNormal=vn, albedo=alb)
+    assert t_ref.sum() > 0 and np.abs(g_ref).max() > 0
+    assert rel_l2(tr, t_ref) <= 1e-5 and np.abs(tr - t_ref).max() <= 1e-6 * t_ref.max()
+    assert rel_l2(grad, g_ref) <= 1e-4
+    assert np.array_equal(path, p_ref)
+    # forward-only entry point gives the same rows (refine 1 / sigma 1 -> plain histogram)
+    if variant == "plain":
+        tr2, path2 = np.zeros((L, T)), np.zeros(T)
+        renderer.renderNonConfocalTransient(a, na, b, nb, v, f, ns, LB, UB, RES, tr2, path2)
+        assert rel_l2(tr2, t0) <= 1e-12
+
+
+def test_nonconfocal_equals_confocal_when_sensor_is_laser(bunny):
+    """sensor == laser reproduces the confocal rows: the BVH path of both kernels accepts the same
+    samples, so the transients are identical up to fp64 summation order."""
+    import torch
+    from nlos_surface_optimization_amd import device as nd
+    v, f = bunny
+    o, n = grid_sources(4, 0.25)
+    dev = torch.device("cuda", 0)
+    r = nd.TransientRenderer(dev, seed=5)
+    tv, tf_ = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
+    to, tn = torch.from_numpy(o).to(dev), torch.from_numpy(n).to(dev)
+    tc, _ = r.render_transient(to, tn, tv, tf_, 20000, LB, UB, RES)
+    tnc, _ = r.render_transient(to, tn, tv, tf_, 20000, LB, UB, RES, sensor=to.clone(), sensor_normal=tn)
+    assert tc.sum().item() > 0
+    assert (tc - tnc).abs().max().item() <= 1e-13 * tc.max().item()
+    data = tc * 1.1
+    w = torch.ones_like(tc)
+    _, gc, _ = r.render_gradient(to, tn, tv, tf_, 20000, LB, UB, RES, data=data, weight=w)
+    _, gnc, _ = r.render_gradient(to, tn, tv, tf_, 20000, LB, UB, RES, data=data, weight=w, sensor=to.clone())
+    assert rel_l2(gnc.cpu().numpy(), gc.cpu().numpy()) <= 1e-5
+    with pytest.raises(Exception):
+        r.render_intensity(to, tn, tv, tf_, 20000, LB, UB, sensor=to.clone())       # rows X/A/GGX are confocal only
