@@ -170,6 +170,37 @@ def render_gradient(origin, normal, v, f, num_sample, lb, ub, res, data, weight,
     return transient, gradient, path
 
 
+def render_jitter(origin, normal, v, f, num_sample, lb, ub, res, jitter_weight, jitter_offset,
+                  jitter_grad=None, data=None, weight=None, testing_flag=1, vnormal=None, albedo=None,
+                  gradient=None, **kw):
+    """jitter/ module: forward (data None) or forward + gradient. Returns (transient, gradient|None, path)."""
+    origin, normal, v, f = _f32(origin), _f32(normal), _f32(v), _i32(f)
+    vnormal, albedo = _f32(vnormal), _f32(albedo)
+    jw = _f64(np.asarray(jitter_weight).ravel())
+    jg = None if jitter_grad is None else _f64(np.asarray(jitter_grad).ravel())
+    L, T = origin.shape[0], num_bins(lb, ub, res)
+    transient = np.zeros((L, T), dtype=np.float64)
+    path = np.zeros(T, dtype=np.float64)
+    if data is not None:
+        data = _f64(data)
+        weight = _f64(np.ones_like(data) if weight is None else weight)
+        if gradient is None:
+            gradient = np.zeros((v.shape[0], 3), dtype=np.float64)
+    o = make_opts(**kw)
+    fn = lib().nlos_oracle_render_jitter
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                   ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                   ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    rc = fn(_p(data), _p(weight), _p(origin), L, _p(normal), _p(v), v.shape[0], _p(vnormal), _p(albedo),
+            _p(f), f.shape[0], int(num_sample), lb, ub, res, _p(jw), _p(jg), int(jitter_offset), jw.shape[0],
+            _p(transient), _p(path), _p(gradient) if data is not None else None, testing_flag, ctypes.byref(o))
+    if rc:
+        raise ValueError("oracle render_jitter failed rc=%d" % rc)
+    return transient, (gradient if data is not None else None), path
+
+
 def render_nonconfocal(laser, laser_normal, sensor, sensor_normal, v, f, num_sample, lb, ub, res,
                        data=None, weight=None, refine=10, sigma_bin=1, testing_flag=1, loss_flag=0,
                        vnormal=None, albedo=None, gradient=None, **kw):

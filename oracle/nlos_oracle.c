@@ -1072,6 +1072,138 @@ int nlos_oracle_render_gradient_v1(const double *data, const float *origin, int 
     return 0;
 }
 
+/* ------------------------------------------------------------------- jitter */
+/* SPAD jitter variant, transient_rendering_cython/jitter/ ("JIT"):
+ * forward = plain histogram convolved with the measured jitter kernel
+ * (JIT/transient_and_gradient.cpp:271-355: y = full conv, transient[b] += y[b + weight_offset]);
+ * gradient taps i -> bin floor((2h-lb)/res) + (i - jitter_offset), weights jitter_weight[i], and the
+ * time-derivative term jitter_grad[i] * I * (-2) * dir / res (JIT/...:944-969). */
+static void jitter_forward(const scene_t *sc, const float *origin, int L, const float *normal,
+                           const float *vnormal, const float *albedo, int num_samples,
+                           float lb, float ub, float res, int nbins, const double *jw, int joff,
+                           int jlen, double *transient, const nlos_oracle_opts *op) {
+    const int nF = sc->nF;
+    const int spt = 1 + ((num_samples - 1) / nF);
+    memset(transient, 0, sizeof(double) * (size_t)L * (size_t)nbins);
+#pragma omp parallel
+    {
+        double *fine = (double *)malloc(sizeof(double) * (size_t)nbins);
+        double *y = (double *)malloc(sizeof(double) * (size_t)(nbins + jlen - 1));
+#pragma omp for schedule(dynamic, 1)
+        for (int l = 0; l < L; ++l) {
+            memset(fine, 0, sizeof(double) * (size_t)nbins);
+            for (int f = 0; f < nF; ++f)
+                forward_task(sc, origin, normal, vnormal, albedo, l, f, lb, ub, res, spt, nbins, fine, op);
+            memset(y, 0, sizeof(double) * (size_t)(nbins + jlen - 1));
+            for (int i = 0; i < nbins; ++i)
+                for (int j = 0; j < jlen; ++j) y[i + j] += fine[i] * jw[j];
+            for (int b = 0; b < nbins; ++b) transient[(size_t)l * nbins + b] += y[b + joff];
+        }
+        free(fine); free(y);
+    }
+}
+
+static void jitter_gradient_task(const scene_t *sc, const float *origin, const float *normal,
+                                 const float *vnormal, int l, int f, float lb, float ub, float res,
+                                 int spt, int nbins, const double *diff_row, const double *jw,
+                                 const double *jg, int joff, int jlen, int normal_term,
+                                 double *grad, const nlos_oracle_opts *op) {
+    task_t t;
+    task_setup(&t, sc, origin, normal, l, f, vnormal, NULL);
+    if (t.degenerate) return;
+    uint64_t kbase = (((uint64_t)(op->source_offset + l)) * (uint64_t)sc->nF + (uint64_t)f) * (uint64_t)spt;
+    const v3 e0 = sub3(t.p2, t.p1), e1 = sub3(t.p0, t.p2), e2 = sub3(t.p1, t.p0);
+    const int vi[3] = {t.i0, t.i1, t.i2};
+    for (int s = 0; s < spt; ++s) {
+        float S, T;
+        geo_t g;
+        gvec_t gv;
+        nlos_oracle_sample(op->seed, kbase + (uint64_t)s, &S, &T);
+        if (!accept_sample(&t, sc, f, op->accel, S, T, lb, ub, &g)) continue;
+        grad_vectors(&t, &g, normal_term, op, 0, &gv);
+        const float bw[3] = {g.u, g.v, g.w};
+        const v3 ce[3] = {cross3(gv.t2, e0), cross3(gv.t2, e1), cross3(gv.t2, e2)};
+        const int b0 = (int)floorf((2.0f * g.h - lb) / res);       /* JIT/...:949-950, float floor */
+        for (int i = 0; i < jlen; ++i) {
+            int bin = b0 + (i - joff);
+            if (bin < 0 || bin >= nbins) continue;                  /* deviation Q3 */
+            float wk = (float)jw[i];
+            /* jitter_grad[i] * intensity * (-2) in double, narrowed when it meets the float vector */
+            v3 tg = scl3(g.dir, (float)(jg[i] * gv.intensity * (-2)));
+            tg = mk(tg.x / res, tg.y / res, tg.z / res);
+            v3 base = add3(scl3(gv.t1, wk), tg);
+            float dd = (float)((-2) * diff_row[bin]);
+            for (int j = 0; j < 3; ++j) {
+                v3 q = add3(scl3(base, bw[j]), scl3(ce[j], wk));
+                q = scl3(q, dd);
+                grad[3 * (size_t)vi[j] + 0] += (double)(t.area * q.x) / (double)spt;
+                grad[3 * (size_t)vi[j] + 1] += (double)(t.area * q.y) / (double)spt;
+                grad[3 * (size_t)vi[j] + 2] += (double)(t.area * q.z) / (double)spt;
+            }
+        }
+    }
+}
+
+/* JIT/stratifiedStreamedGradientRenderer.cpp:475-578 (gradient != NULL) and
+ * JIT/stratifiedStreamedTransientRenderer.cpp (forward only: data == NULL / gradient == NULL).
+ * jitter_grad may be NULL for the forward-only call. */
+int nlos_oracle_render_jitter(const double *data, const double *weight,
+                              const float *origin, int L, const float *normal,
+                              const float *V, int nV, const float *vnormal, const float *albedo,
+                              const int32_t *F, int nF, int num_samples,
+                              float lb, float ub, float res,
+                              const double *jitter_weight, const double *jitter_grad,
+                              int jitter_offset, int jitter_length,
+                              double *transient, double *pathlengths, double *gradient,
+                              int testing_flag, const nlos_oracle_opts *opts) {
+    nlos_oracle_opts dflt;
+    if (!opts) { nlos_oracle_default_opts(&dflt); opts = &dflt; }
+    if (nF <= 0 || L < 0 || jitter_length < 1 || jitter_offset < 0 || jitter_offset >= jitter_length) return -1;
+    scene_t sc;
+    if (scene_init(&sc, V, nV, F, nF, opts->accel)) return -1;
+    const int nbins = nlos_oracle_num_bins(lb, ub, res);
+    const int spt = 1 + ((num_samples - 1) / nF);
+    if (pathlengths) fill_pathlengths(pathlengths, nbins, lb, res);
+#ifdef _OPENMP
+    if (opts->threads > 0) omp_set_num_threads(opts->threads);
+#endif
+    jitter_forward(&sc, origin, L, normal, vnormal, albedo, num_samples, lb, ub, res, nbins,
+                   jitter_weight, jitter_offset, jitter_length, transient, opts);
+    if (data && gradient && jitter_grad) {
+        size_t n = (size_t)L * (size_t)nbins;
+        double *diff = (double *)malloc(sizeof(double) * (n ? n : 1));
+        residual(data, weight, transient, n, 0, diff);
+        int nt = opts->normal_term < 0 ? (testing_flag == 0 && vnormal != NULL) : opts->normal_term;
+        int nth = 1;
+#ifdef _OPENMP
+        nth = omp_get_max_threads();
+#endif
+        double *priv = (double *)calloc((size_t)nth * 3 * (size_t)nV, sizeof(double));
+#pragma omp parallel
+        {
+            int tid = 0;
+#ifdef _OPENMP
+            tid = omp_get_thread_num();
+#endif
+            double *mine = priv + (size_t)tid * 3 * (size_t)nV;
+#pragma omp for schedule(dynamic, 64)
+            for (long long idx = 0; idx < (long long)L * nF; ++idx) {
+                int f = (int)(idx % nF), l = (int)(idx / nF);
+                jitter_gradient_task(&sc, origin, normal, vnormal, l, f, lb, ub, res, spt, nbins,
+                                     diff + (size_t)l * nbins, jitter_weight, jitter_grad, jitter_offset,
+                                     jitter_length, nt, mine, opts);
+            }
+        }
+        const int Ltot = opts->total_sources > 0 ? opts->total_sources : L;
+        for (int th = 0; th < nth; ++th)
+            for (size_t i = 0; i < 3 * (size_t)nV; ++i)
+                gradient[i] += priv[(size_t)th * 3 * (size_t)nV + i] / Ltot;
+        free(priv); free(diff);
+    }
+    scene_free(&sc);
+    return 0;
+}
+
 /* ------------------------------------------------------------ non-confocal */
 /* Row N: laser point a != sensor point b.  The reference has no native
  * kernel for it; its prototypes (transient_rendering_python/rendering.py:37-93, angular sampling;

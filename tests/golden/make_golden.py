@@ -11,6 +11,7 @@ Reads /root/reference (read-only, absent on the GPU box) and writes DATA only:
                       closest-hit / distance / binning primitives against reference code
   pyref_angular_nc.npz  the same prototype with lighting != sensor (row N, non-confocal pairs), incl. a
                       blocker that hides paths from one end point only
+  jitter_info.npz     jitter/jitter_info.mat (the reference's measured SPAD jitter kernel) as npz
   oracle_cfg1.npz     oracle transient + gradient for BASELINE config 1 (regression pin)
   oracle_bunny16.npz  oracle transient + gradient, bunny_5k, 16 sources (regression pin)
   ggx_table.npz       oracle GGX eval / eval_adiff / eval_nwdiff over an (alpha, n.w) grid
@@ -172,6 +173,15 @@ def make_pyref_nc():
     np.savez_compressed(os.path.join(HERE, "pyref_angular_nc.npz"), **out)
 
 
+def make_jitter_info():
+    """The reference's measured SPAD jitter kernel (a data file its own jitter/test.py loads)."""
+    import scipy.io
+    j = scipy.io.loadmat(os.path.join(REF, "transient_rendering_cython/jitter/jitter_info.mat"))
+    np.savez_compressed(os.path.join(HERE, "jitter_info.npz"), jitter_weight=j["jitter_weight"],
+                        jitter_grad=j["jitter_grad"], jitter_offset=np.int64(j["jitter_offset"][0, 0]),
+                        jitter_time=j["jitter_time"])
+
+
 def make_oracle_cfg1():
     v, f, origin, normal = cfg1()
     lb, ub, res = 0.0, 2.0, 2.0 ** -5
@@ -224,6 +234,7 @@ if __name__ == "__main__":
     bv, bf = make_meshes()
     make_pyref()
     make_pyref_nc()
+    make_jitter_info()
     make_oracle_cfg1()
     make_oracle_bunny(bv, bf)
     make_ggx_table()

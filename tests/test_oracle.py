@@ -371,3 +371,62 @@ def test_nonconfocal_gradient_against_finite_differences(orc):
             fd[i, c] = (loss(vp.astype(np.float32)) - loss(vm.astype(np.float32))) / (
                 float(np.float32(vp[i, c])) - float(np.float32(vm[i, c])))
     assert rel_l2(g, fd) < 0.02, (rel_l2(g, fd), g, fd)     # 0.9 % here; 0.3 % at refine 48, sigma_bin 8
+
+
+# ------------------------------------------------------------------ jitter/ module
+def test_jitter_forward_is_histogram_convolved_with_kernel(orc, bunny):
+    """jitter/transient_and_gradient.cpp:331-347 on the reference's own measured kernel
+    (jitter/jitter_info.mat, committed as data): row = full conv(histogram, w)[offset : offset+T]."""
+    v, f = bunny
+    j = np.load(os.path.join(GOLDEN, "jitter_info.npz"))
+    jw, jo = j["jitter_weight"], int(j["jitter_offset"])
+    assert jw.shape == (40, 1) and jo == 8
+    assert np.allclose(j["jitter_grad"].ravel()[1:-1], np.gradient(jw.ravel())[1:-1])     # what jitter_grad is
+    o, n = grid_sources(2, 0.1)
+    lb, ub, res = 0.0, float(np.float32(1200 * 0.0012)), 0.0012                           # jitter/test.py:41-45
+    t0, _ = orc.render_transient(o, n, v, f, 20000, lb, ub, res, accel=1)
+    tj, _, path = orc.render_jitter(o, n, v, f, 20000, lb, ub, res, jw, jo, accel=1)
+    assert t0.shape == (4, 1200)
+    for l in range(4):
+        y = np.convolve(t0[l], jw.ravel())
+        assert np.allclose(tj[l], y[jo:jo + 1200], rtol=0, atol=1e-15)
+    td, _, _ = orc.render_jitter(o, n, v, f, 20000, lb, ub, res, np.array([[1.0]]), 0, accel=1)
+    assert np.abs(td - t0).max() <= 1e-16                                                  # delta kernel (jitter/test.py:60-62)
+
+
+def test_jitter_gradient_against_finite_differences(orc):
+    """With a wide smooth kernel w and jitter_grad = dw/d(tap) the analytic gradient matches central
+    differences of loss = sum w (data - conv(hist, w))^2 / L; without the jitter_grad term it does not."""
+    v = np.array([[-.11, -.07, .42], [.12, -.09, .47], [.02, .13, .40]], np.float32)
+    f = np.array([[0, 2, 1]], np.int32)
+    a = np.array([[0.05, -0.02, 0], [-0.15, 0.1, 0]], np.float32)
+    n = np.tile(np.array([0, 0, 1], np.float32), (2, 1))
+    lb, ub, res, ns = 0.5, 1.5, 2.0 ** -8, 8192
+    T = orc.num_bins(lb, ub, res)
+    rs = np.random.RandomState(3)
+    data = rs.random_sample((2, T)) * 0.02
+    w = 0.5 + rs.random_sample((2, T))
+    sig = 24
+    x = np.arange(8 * sig + 1) - 4 * sig
+    jw = np.exp(-x ** 2 / (2 * sig ** 2)) / (sig * np.sqrt(2 * np.pi))
+    jg = -x / sig ** 2 * jw
+
+    def loss(vv):
+        t, _, _ = orc.render_jitter(a, n, vv, f, ns, lb, ub, res, jw, 4 * sig)
+        return float(np.sum(w * (data - t) ** 2) / 2)
+
+    _, g, _ = orc.render_jitter(a, n, v, f, ns, lb, ub, res, jw, 4 * sig, jitter_grad=jg, data=data, weight=w,
+                                testing_flag=0, normal_term=1)
+    _, g0, _ = orc.render_jitter(a, n, v, f, ns, lb, ub, res, jw, 4 * sig, jitter_grad=0 * jg, data=data, weight=w,
+                                 testing_flag=0, normal_term=1)
+    fd = np.zeros((3, 3))
+    eps = 1e-3
+    for i in range(3):
+        for c in range(3):
+            vp, vm = v.astype(np.float64).copy(), v.astype(np.float64).copy()
+            vp[i, c] += eps
+            vm[i, c] -= eps
+            fd[i, c] = (loss(vp.astype(np.float32)) - loss(vm.astype(np.float32))) / (
+                float(np.float32(vp[i, c])) - float(np.float32(vm[i, c])))
+    assert rel_l2(g, fd) < 0.02, rel_l2(g, fd)                 # 0.4 % here
+    assert rel_l2(g0, fd) > 4 * rel_l2(g, fd)
