@@ -381,7 +381,8 @@ def test_jitter_forward_is_histogram_convolved_with_kernel(orc, bunny):
     j = np.load(os.path.join(GOLDEN, "jitter_info.npz"))
     jw, jo = j["jitter_weight"], int(j["jitter_offset"])
     assert jw.shape == (40, 1) and jo == 8
-    assert np.allclose(j["jitter_grad"].ravel()[1:-1], np.gradient(jw.ravel())[1:-1])     # what jitter_grad is
+    # what jitter_grad is: the kernel's derivative per tap (central differences, to ~1 % of its peak)
+    assert np.abs(j["jitter_grad"].ravel() - np.gradient(jw.ravel()))[1:-1].max() < 0.02 * np.abs(j["jitter_grad"]).max()
     o, n = grid_sources(2, 0.1)
     lb, ub, res = 0.0, float(np.float32(1200 * 0.0012)), 0.0012                           # jitter/test.py:41-45
     t0, _ = orc.render_transient(o, n, v, f, 20000, lb, ub, res, accel=1)
