@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE config 2 (parity-run size, not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--non-confocal", action="store_true",
+                    help="row N side measurement (not the metric): every source becomes a (laser, sensor) pair, "
+                         "sensor = laser + (0.05, -0.03, 0)")
     args = ap.parse_args()
 
     import torch
@@ -154,16 +157,19 @@ def main():
                                  source_offset=lo, total_sources=L_total, seed=1)
     weight = torch.ones_like(data)
     grad = torch.zeros((V, 3), dtype=torch.float64, device=dev)
+    nc = {}
+    if args.non_confocal:
+        nc = {"sensor": (origin + torch.tensor([0.05, -0.03, 0.0], device=dev)).contiguous(), "sensor_normal": normal}
 
     def step():
         grad.zero_()
         if args.forward_only:
             r.render_transient(origin, normal, verts, faces, args.num_sample, lb, ub, res,
-                               source_offset=lo, total_sources=L_total)
+                               source_offset=lo, total_sources=L_total, **nc)
         else:
             r.render_gradient(origin, normal, verts, faces, args.num_sample, lb, ub, res, data=data,
                               weight=weight, refine_scale=10, sigma_bin=1, testing_flag=1, loss_flag=0,
-                              gradient=grad, source_offset=lo, total_sources=L_total)
+                              gradient=grad, source_offset=lo, total_sources=L_total, **nc)
             if world > 1:
                 dist.all_reduce(grad, op=dist.ReduceOp.SUM)
 
@@ -204,7 +210,8 @@ def main():
             "dtype": "f32 per-sample math, f64 accumulation",
             "data": "synthetic",
             "config": {
-                "workload": ("forward-only " if args.forward_only else "forward+gradient ") +
+                "workload": ("NON-CONFOCAL pairs (row N side measurement, not the metric) " if args.non_confocal else "") +
+                            ("forward-only " if args.forward_only else "forward+gradient ") +
                             "%dx%d confocal sources per GPU x %d bins, bunny_5k (F=%d, V=%d), num_sample=%d "
                             "(spt=%d), refine=10, sigma_bin=1, BVH rebuilt every step" % (g, g, T, F, V, args.num_sample, spt),
                 "sources_total": L_total, "faces": F, "bins": T, "spt": spt,
@@ -220,14 +227,14 @@ def main():
             achieved = per_sample * local_samples / (kt[dom] * 1e-3) / 1e9
             pmc = load_pmc_traffic()
             traffic = None
-            if pmc and pmc.get("kernel") == names[dom] and pmc.get("L") == L and pmc.get("F") == F:
+            if pmc and not args.non_confocal and pmc.get("kernel") == names[dom] and pmc.get("L") == L and pmc.get("F") == F:
                 traffic = pmc.get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_sample": per_sample,
                                "kernel_ms": {n: float(x) for n, x in zip(names, kt)},
                                "step_algorithmic_GBps": (200.0 + 72.0 / spt) * local_samples / (ms * 1e-3) / 1e9}
-        if world == 1 and not args.no_cpu_baseline and not args.forward_only:
+        if world == 1 and not args.no_cpu_baseline and not args.forward_only and not args.non_confocal:
             out["cpu_baseline"] = cpu_baseline(v_np, f_np, origin_np, normal_np, lb, ub, res, args.num_sample,
                                                data.cpu().numpy())
         print(json.dumps(out))

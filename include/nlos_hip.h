@@ -133,6 +133,20 @@ int nlos_nonconfocal_render_gradient(double *data, double *weight, float *laser,
         float resolution, double *transient, double *pathlengths, double *gradient,
         int refine_scale, int sigma_bin, int testing_flag, int loss_test);
 
+/* jitter/stratifiedStreamedTransientRenderer.h, jitter/stratifiedStreamedGradientRenderer.h:10
+ * (the `jitter` extension module: measured SPAD jitter kernel instead of the Gaussian) */
+int nlos_jitter_streamed_render_transient(float *origin, int numSources, float *normal,
+        float *vertices, int numVertices, float *vertexNormal, float *vertexAlbedo,
+        int *triangles, int numTriangles, int numSamples, float lowerBound,
+        float upperBound, float resolution, double *weight, int weight_offset,
+        int weight_length, double *transient, double *pathlengths);
+int nlos_jitter_streamed_render_gradient(double *data, double *weight, float *origin,
+        int measurement, float *normal, float *vertices, int numVertices,
+        float *vertexNormal, int *triangles, int numTriangles, int numSamples,
+        float lowerBound, float upperBound, float resolution, double *jitter_weight,
+        double *jitter_grad, int weight_offset, int weight_length, double *transient,
+        double *pathlengths, double *gradient, int testing_flag);
+
 /* embree_intersector/c_embree_intersector.h:3-9 */
 int nlos_embree3_tbb_line_intersection(float *origins, float *directions, int num_ray,
         float *vertices, int num_vertices, int *triangles, int num_triangles,
@@ -227,6 +241,15 @@ typedef struct nlos_render_args {
      * GRADIENT modes, Lambertian only. */
     const float *sensor;        /* [L,3] or NULL */
     const float *sensor_normal; /* [L,3] (required with sensor) */
+    /* SPAD jitter variant (the reference's `jitter` module: jitter/transient_and_gradient.cpp:271-355,
+     * :944-969).  jitter_weight != NULL (TRANSIENT / GRADIENT modes, confocal, Lambertian): the
+     * forward rows are the plain histogram convolved with jitter_weight (transient[b] = y[b +
+     * jitter_offset], y the full convolution) and the gradient uses tap i -> bin floor((2h-lb)/res)
+     * + i - jitter_offset with weight jitter_weight[i] and time-derivative weight jitter_grad[i];
+     * refine_scale / sigma_bin are ignored. */
+    const double *jitter_weight; /* [jitter_length] or NULL */
+    const double *jitter_grad;   /* [jitter_length] (GRADIENT mode) */
+    int32_t jitter_offset, jitter_length;
 } nlos_render_args;
 
 int  nlos_sizeof_render_args(void);                 /* for FFI layout checks */

@@ -4,7 +4,7 @@ The one data-parallel hot path of cmu-ci-lab/nlos_surface_optimization (stratifi
 confocal transient rendering + analytic per-vertex gradient + closest-hit queries) as
 hand-written HIP kernels for gfx950 behind the reference's own module names:
 
-    from nlos_surface_optimization_amd import renderer, ggx, embree_intersector, rendering
+    from nlos_surface_optimization_amd import renderer, ggx, jitter, embree_intersector, rendering
 
 `renderer` / `ggx` / `embree_intersector` mirror the reference's Cython extension modules
 (numpy in, in-place numpy out); `rendering` mirrors its facade; `device` is the additive
@@ -12,9 +12,9 @@ torch-tensor / autograd path and `dist` the multi-GPU source sharding.  There is
 fallback: without libnlos_hip.so and an AMD GPU every render call raises.
 """
 from . import _lib  # noqa: F401
-from . import embree_intersector, ggx, renderer, renderer_v1, rendering, rendering_v1  # noqa: F401
+from . import embree_intersector, ggx, jitter, renderer, renderer_v1, rendering, rendering_v1  # noqa: F401
 
-__all__ = ["renderer", "renderer_v1", "ggx", "embree_intersector", "rendering", "rendering_v1",
+__all__ = ["renderer", "renderer_v1", "ggx", "jitter", "embree_intersector", "rendering", "rendering_v1",
            "device", "dist", "mesh_io"]
 
 

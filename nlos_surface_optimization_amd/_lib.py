@@ -66,6 +66,10 @@ class RenderArgs(ctypes.Structure):
         ("force_bvh", ctypes.c_int32),
         ("sensor", ctypes.c_void_p),
         ("sensor_normal", ctypes.c_void_p),
+        ("jitter_weight", ctypes.c_void_p),
+        ("jitter_grad", ctypes.c_void_p),
+        ("jitter_offset", ctypes.c_int32),
+        ("jitter_length", ctypes.c_int32),
     ]
 
 
@@ -95,6 +99,8 @@ SYMBOLS = {
     "nlos_ggx_streamed_render_gradient_alpha": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _F, _I, _F, _F, _F, _P, _P, _I, _I, _P]),
     "nlos_v1_streamed_render_gradient": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _I, _P, _P, _P]),
     "nlos_v1_streamed_render_transient": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P]),
+    "nlos_jitter_streamed_render_transient": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _P, _I, _I, _P, _P]),
+    "nlos_jitter_streamed_render_gradient": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F, _P, _P, _I, _I, _P, _P, _P, _I]),
     "nlos_nonconfocal_render_transient": (_I, [_P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _I, _I]),
     "nlos_nonconfocal_render_gradient": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _I, _I, _I, _I]),
     "nlos_embree3_tbb_line_intersection": (_I, [_P, _P, _I, _P, _I, _P, _I, _P]),

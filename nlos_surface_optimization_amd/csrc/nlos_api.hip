@@ -383,6 +383,16 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     if (mode < 0 || mode > NLOS_MODE_GRADIENT_V1) return fail(NLOS_ERR_ARG, "nlos_render: unknown mode");
     if (mode == NLOS_MODE_VERTEX_GRADIENT && (a->vertex_num < 0 || a->vertex_num >= a->V))
         return fail(NLOS_ERR_ARG, "nlos_render: vertex_num out of range");
+    const bool jitter = a->jitter_weight != nullptr;
+    if (jitter) {
+        if (mode != NLOS_MODE_TRANSIENT && mode != NLOS_MODE_GRADIENT)
+            return fail(NLOS_ERR_ARG, "nlos_render: the jitter kernel applies to TRANSIENT and GRADIENT modes only");
+        if (a->jitter_length < 1 || a->jitter_offset < 0 || a->jitter_offset >= a->jitter_length)
+            return fail(NLOS_ERR_ARG, "nlos_render: need 0 <= jitter_offset < jitter_length");
+        if (mode == NLOS_MODE_GRADIENT && !a->jitter_grad) return fail(NLOS_ERR_ARG, "nlos_render: jitter_grad is NULL");
+        if (a->use_ggx || a->sensor || !a->clamp || (mode == NLOS_MODE_GRADIENT && a->albedo))
+            return fail(NLOS_ERR_ARG, "nlos_render: the jitter variant is confocal, Lambertian, without per-vertex albedo in the gradient");
+    }
     if (a->sensor) {
         if (!a->sensor_normal) return fail(NLOS_ERR_ARG, "nlos_render: sensor needs sensor_normal");
         if (mode != NLOS_MODE_TRANSIENT && mode != NLOS_MODE_GRADIENT)
@@ -426,7 +436,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     int fwd_refine = a->refine_scale;
     // smoothed_transient/stratifiedStreamedGradientRenderer.cpp:521-524
     if (two_pass) fwd_refine = a->sigma_bin < 5 ? 1 : a->refine_scale;
-    if (mode == NLOS_MODE_GRADIENT_V1 || mode == NLOS_MODE_INTENSITY) fwd_refine = 1;
+    if (mode == NLOS_MODE_GRADIENT_V1 || mode == NLOS_MODE_INTENSITY || jitter) fwd_refine = 1;
     const int rb = T * fwd_refine;
 
     nlos::ForwardArgs fa;
@@ -479,7 +489,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         transient = c->rows_tmp.as<double>();
     }
     if (mode != NLOS_MODE_INTENSITY) {
-        if (fwd_refine > 1) {
+        if (fwd_refine > 1 || jitter) {
             rc = c->fine.ensure(sizeof(double) * (size_t)L * rb + 16);
             if (rc) return rc;
             fa.rows = c->fine.as<double>();
@@ -513,6 +523,14 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         nlos::SmoothArgs sm;
         sm.fine = c->fine.as<double>(); sm.transient = transient; sm.kernel = c->taps.as<double>();
         sm.L = L; sm.T = T; sm.refine = fwd_refine; sm.sigma_bin = a->sigma_bin; sm.K = K;
+        sm.offset = 2 * fwd_refine * a->sigma_bin;
+        nlos::launch_smooth(sm, st);
+    }
+    if (!skip_pass1 && jitter) {
+        // jitter/transient_and_gradient.cpp:331-347: row = conv(histogram, jitter_weight)[offset : offset + T]
+        nlos::SmoothArgs sm;
+        sm.fine = c->fine.as<double>(); sm.transient = transient; sm.kernel = a->jitter_weight;
+        sm.L = L; sm.T = T; sm.refine = 1; sm.sigma_bin = 0; sm.K = a->jitter_length; sm.offset = a->jitter_offset;
         nlos::launch_smooth(sm, st);
     }
     mark(c, 2, st);
@@ -551,7 +569,8 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     // ---- pass 2 -----------------------------------------------------------------------
     if (two_pass) {
         int K = 0;
-        rc = ensure_taps(c, mode == NLOS_MODE_GRADIENT_V1 ? 1 : 0, a->refine_scale, a->sigma_bin, res, st, &K);
+        if (jitter) K = a->jitter_length;
+        else rc = ensure_taps(c, mode == NLOS_MODE_GRADIENT_V1 ? 1 : 0, a->refine_scale, a->sigma_bin, res, st, &K);
         if (rc) return rc;
         nlos::GradientArgs ga;
         ga.sc = sc; ga.src = src; ga.sp = sp;
@@ -571,6 +590,12 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
                 ga.mode = 0;
                 ga.normal_term = a->normal_term < 0 ? ((a->testing_flag == 0 && vn != nullptr) ? 1 : 0) : (a->normal_term ? 1 : 0);
                 ga.out = a->gradient;
+                if (jitter) {
+                    ga.mode = 4;
+                    ga.tap_w = a->jitter_weight; ga.tap_g = a->jitter_grad;
+                    ga.tap_delta = ga.tap_p0 = ga.tap_p1 = nullptr;
+                    ga.two_rs = a->jitter_offset;
+                }
                 break;
             case NLOS_MODE_GRADIENT_V1:
                 ga.mode = 0; ga.normal_term = 1; ga.out = a->gradient;
@@ -591,7 +616,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
                 break;
         }
         // LDS: diff row + tap tables + 3V accumulator + live-face list (4.2 B per face)
-        ga.lds_grad = (ga.mode == 0 && (3 * (size_t)nV + (size_t)T + 3 * (size_t)K + 2) * sizeof(double) +
+        ga.lds_grad = ((ga.mode == 0 || ga.mode == 4) && (3 * (size_t)nV + (size_t)T + 3 * (size_t)K + 2) * sizeof(double) +
                                            5 * (size_t)nF + 128 <= (size_t)nlos::kGradLdsBudget) ? 1 : 0;
         nlos::launch_gradient(ga, st);
     }
@@ -674,6 +699,8 @@ struct HostRender {
     double *data = nullptr, *weight = nullptr;
     float *origin = nullptr, *normal = nullptr, *vertices = nullptr, *vnormal = nullptr, *albedo = nullptr;
     float *sensor = nullptr, *sensor_normal = nullptr;
+    double *jitter_weight = nullptr, *jitter_grad = nullptr;
+    int jitter_offset = 0, jitter_length = 0;
     int* faces = nullptr;
     int L = 0, V = 0, F = 0, num_samples = 0;
     float lb = 0, ub = 0, res = 1;
@@ -702,6 +729,9 @@ int host_render(const HostRender& h) {
     a.normal = hc.up(h.normal, 3 * (size_t)h.L);
     a.sensor = hc.up(h.sensor, 3 * (size_t)h.L);
     a.sensor_normal = hc.up(h.sensor_normal, 3 * (size_t)h.L);
+    a.jitter_weight = hc.up(h.jitter_weight, (size_t)h.jitter_length);
+    a.jitter_grad = hc.up(h.jitter_grad, (size_t)h.jitter_length);
+    a.jitter_offset = h.jitter_offset; a.jitter_length = h.jitter_length;
     a.L = h.L; a.source_offset = 0; a.total_sources = h.L;
     a.vertices = hc.up(h.vertices, 3 * (size_t)h.V); a.V = h.V;
     a.faces = hc.up(h.faces, 3 * (size_t)h.F); a.F = h.F;
@@ -783,6 +813,42 @@ int nlos_nonconfocal_render_gradient(double* data, double* weight, float* laser,
     h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
     h.transient = transient; h.pathlengths = pathlengths; h.gradient = gradient;
     h.refine = refine_scale; h.sigma_bin = sigma_bin; h.testing_flag = testing_flag; h.loss_test = loss_test;
+    return host_render(h);
+}
+
+int nlos_jitter_streamed_render_transient(float* origin, int numSources, float* normal, float* vertices,
+                                          int numVertices, float* vertexNormal, float* vertexAlbedo, int* triangles,
+                                          int numTriangles, int numSamples, float lowerBound, float upperBound,
+                                          float resolution, double* weight, int weight_offset, int weight_length,
+                                          double* transient, double* pathlengths) {
+    if (!weight || weight_length < 1) return fail(NLOS_ERR_ARG, "jitter render: weight is NULL / empty");
+    HostRender h;
+    h.mode = NLOS_MODE_TRANSIENT;
+    h.origin = origin; h.L = numSources; h.normal = normal; h.vertices = vertices; h.V = numVertices;
+    h.vnormal = vertexNormal; h.albedo = vertexAlbedo; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.jitter_weight = weight; h.jitter_offset = weight_offset; h.jitter_length = weight_length;
+    h.transient = transient; h.pathlengths = pathlengths;
+    return host_render(h);
+}
+
+int nlos_jitter_streamed_render_gradient(double* data, double* weight, float* origin, int measurement, float* normal,
+                                         float* vertices, int numVertices, float* vertexNormal, int* triangles,
+                                         int numTriangles, int numSamples, float lowerBound, float upperBound,
+                                         float resolution, double* jitter_weight, double* jitter_grad,
+                                         int weight_offset, int weight_length, double* transient,
+                                         double* pathlengths, double* gradient, int testing_flag) {
+    if (!jitter_weight || !jitter_grad || weight_length < 1) return fail(NLOS_ERR_ARG, "jitter render: jitter arrays are NULL / empty");
+    HostRender h;
+    h.mode = NLOS_MODE_GRADIENT;
+    h.data = data; h.weight = weight;
+    h.origin = origin; h.L = measurement; h.normal = normal; h.vertices = vertices; h.V = numVertices;
+    h.vnormal = vertexNormal; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.jitter_weight = jitter_weight; h.jitter_grad = jitter_grad; h.jitter_offset = weight_offset;
+    h.jitter_length = weight_length;
+    h.transient = transient; h.pathlengths = pathlengths; h.gradient = gradient;
+    h.testing_flag = testing_flag;
     return host_render(h);
 }
 

@@ -83,6 +83,7 @@ struct SmoothArgs {
     double* transient;       // [L, T]
     const double* kernel;    // [K]
     int L, T, refine, sigma_bin, K;
+    int offset;              // y index of output bin 0 (2*refine*sigma_bin for the Gaussian, jitter_offset for row J)
 };
 void launch_smooth(const SmoothArgs& a, hipStream_t stream);
 
@@ -118,7 +119,9 @@ struct GradientArgs {
     double r_over_res;       // refine / resolution
     int normal_term;         // 0/1 (already resolved)
     int v1_style;            // 1: G1 (t1 without albedo)
-    int mode;                // 0 vertex gradient [V,3], 1 scalar albedo, 2 scalar alpha, 3 single vertex per bin
+    int mode;                // 0 vertex gradient [V,3], 1 scalar albedo, 2 scalar alpha, 3 single vertex per bin,
+                             // 4 vertex gradient with jitter taps (tap_w = jitter_weight, tap_g = jitter_grad,
+                             //   K = jitter_length, two_rs = jitter_offset; delta/p0/p1 unused)
     int vertex_num;
     double* out;             // gradient [V,3] | scalar [1] | [T,3]
     int lds_grad;            // 1: per-workgroup LDS accumulator (3V doubles) fits

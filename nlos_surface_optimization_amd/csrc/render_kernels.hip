@@ -958,7 +958,7 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
 // --------------------------------------------------------------------- smooth
 __global__ __launch_bounds__(256) void k_smooth(SmoothArgs a) {
     const int l = blockIdx.x;
-    const int R = a.refine, K = a.K, half = 2 * a.refine * a.sigma_bin;
+    const int R = a.refine, K = a.K, half = a.offset;
     const int rb = a.T * R;
     const double* fine = a.fine + (size_t)l * rb;
     for (int t = threadIdx.x; t < a.T; t += blockDim.x) {
@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(512, 4) void k_gradient(GradientArgs a) {
     double* s_p0 = s_delta + K;             // [K+1]
     double* s_p1 = s_p0 + K + 1;            // [K+1]
     double* s_grad = s_p1 + K + 1;          // [3V] when lds_grad
-    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(s_grad + ((MODE == 0 && a.lds_grad) ? 3 * V : 0));
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(s_grad + (((MODE == 0 || MODE == 4) && a.lds_grad) ? 3 * V : 0));
     uint32_t* s_base = reinterpret_cast<uint32_t*>(s_mask + nblocks);              // [nblocks+1]
     uint32_t* s_live = s_base + ((nblocks + 2) & ~1);                               // [F] sorted face slots
     const int spt = a.sp.spt;
@@ -1173,9 +1173,14 @@ __global__ __launch_bounds__(512, 4) void k_gradient(GradientArgs a) {
     const int Ltot = a.src.total_sources > 0 ? a.src.total_sources : a.src.L;
     const double lbd = (double)a.sp.lb, resd = (double)a.sp.res, inv_res = 1.0 / resd;
 
-    for (int i = threadIdx.x; i < K; i += blockDim.x) s_delta[i] = a.tap_delta[i];
-    for (int i = threadIdx.x; i <= K; i += blockDim.x) { s_p0[i] = a.tap_p0[i]; s_p1[i] = a.tap_p1[i]; }
-    if (MODE == 0 && a.lds_grad)
+    if (MODE == 4) {
+        // jitter taps: s_delta <- (float) jitter_weight, s_p0 <- jitter_grad
+        for (int i = threadIdx.x; i < K; i += blockDim.x) { s_delta[i] = (double)(float)a.tap_w[i]; s_p0[i] = a.tap_g[i]; }
+    } else {
+        for (int i = threadIdx.x; i < K; i += blockDim.x) s_delta[i] = a.tap_delta[i];
+        for (int i = threadIdx.x; i <= K; i += blockDim.x) { s_p0[i] = a.tap_p0[i]; s_p1[i] = a.tap_p1[i]; }
+    }
+    if ((MODE == 0 || MODE == 4) && a.lds_grad)
         for (int i = threadIdx.x; i < 3 * V; i += blockDim.x) s_grad[i] = 0.0;
     double scalar_acc = 0.0;
     TapTables tt;
@@ -1323,8 +1328,25 @@ __global__ __launch_bounds__(512, 4) void k_gradient(GradientArgs a) {
                     // MODE 0: the K-tap loop factors into two scalar sums per sample:
                     //   sum_i (t1*b + t2 x e) w_i d_i  +  b * I * dir * sum_i g_i w_i d_i
                     double s0, s1;
-                    grouped_taps(tt, s_diff, T, twoh, lbd, resd, inv_res, s0, s1);
-                    const V3 di = g.dir * gv.inten_f;
+                    V3 di;
+                    if (MODE == 4) {
+                        // jitter/transient_and_gradient.cpp:944-969: tap i -> bin b0 + (i - offset),
+                        //   g = (t1 w_i + jitter_grad_i * I * (-2) * dir / res) * b + (t2 x e) w_i
+                        const int b0 = (int)floorf((2.0f * g.h - a.sp.lb) / a.sp.res) - a.two_rs;
+                        const double m2i = (double)gv.inten_f * (-2);
+                        s0 = 0.0;
+                        s1 = 0.0;
+                        const int i0 = max(0, -b0), i1 = min(K, T - b0);
+                        for (int i = i0; i < i1; ++i) {
+                            const float dd = (float)((-2) * s_diff[b0 + i]);
+                            s0 += (double)((float)s_delta[i] * dd);
+                            s1 += (double)(((float)(s_p0[i] * m2i) / a.sp.res) * dd);
+                        }
+                        di = g.dir;
+                    } else {
+                        grouped_taps(tt, s_diff, T, twoh, lbd, resd, inv_res, s0, s1);
+                        di = g.dir * gv.inten_f;
+                    }
                     const float bw[3] = {g.u, g.v, g.w};
                     const V3 ce[3] = {ce0, ce1, ce2};
 #pragma unroll
@@ -1337,7 +1359,7 @@ __global__ __launch_bounds__(512, 4) void k_gradient(GradientArgs a) {
                     }
                 }
             }
-            if (MODE == 0) {
+            if (MODE == 0 || MODE == 4) {
                 const double sc = (double)f.area / (double)spt;
                 const int vi[3] = {f.i0, f.i1, f.i2};
 #pragma unroll
@@ -1355,7 +1377,7 @@ __global__ __launch_bounds__(512, 4) void k_gradient(GradientArgs a) {
         }
     }
     __syncthreads();
-    if (MODE == 0 && a.lds_grad) {
+    if ((MODE == 0 || MODE == 4) && a.lds_grad) {
         const double invL = 1.0 / (double)Ltot;
         for (int i = threadIdx.x; i < 3 * V; i += blockDim.x) {
             double v = s_grad[i];
@@ -1467,6 +1489,9 @@ void gradient_launch(const GradientArgs& a, int grid, size_t lds, hipStream_t st
         case 0: gradient_launch2<FEAT, 0>(a, grid, lds, stream); break;
         case 1: gradient_launch2<FEAT, 1>(a, grid, lds, stream); break;
         case 2: gradient_launch2<FEAT, 2>(a, grid, lds, stream); break;
+        case 4:
+            if constexpr ((FEAT & (FEAT_GGX | FEAT_ALB)) == 0) gradient_launch2<FEAT, 4>(a, grid, lds, stream);
+            break;
         default: gradient_launch2<FEAT, 3>(a, grid, lds, stream); break;
     }
 }
@@ -1514,7 +1539,7 @@ void launch_residual(const ResidualArgs& a, hipStream_t stream) {
 void launch_gradient(const GradientArgs& a, hipStream_t stream) {
     if (a.src.L <= 0) return;
     size_t lds = 8 + ((size_t)a.sp.nbins + 3 * (size_t)a.K + 2) * sizeof(double);
-    if (a.mode == 0 && a.lds_grad) lds += 3 * (size_t)a.sc.V * sizeof(double);
+    if ((a.mode == 0 || a.mode == 4) && a.lds_grad) lds += 3 * (size_t)a.sc.V * sizeof(double);
     const size_t nblk = ((size_t)a.sc.F + 63) / 64;
     lds += nblk * 8 + ((nblk + 2) & ~(size_t)1) * 4 + (size_t)a.sc.F * 4;
     // persistent workgroups: as many as can be co-resident (512 threads each)

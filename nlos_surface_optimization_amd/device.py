@@ -93,7 +93,7 @@ class TransientRenderer:
     def _args(self, mode, origin, normal, vertices, faces, num_sample, lower_bound, upper_bound,
               resolution, refine_scale=1, sigma_bin=1, vertex_normal=None, albedo=None,
               source_offset=0, total_sources=0, alpha=None, seed=None, force_bvh=False,
-              sensor=None, sensor_normal=None):
+              sensor=None, sensor_normal=None, jitter_weight=None, jitter_grad=None, jitter_offset=0):
         a = _lib.RenderArgs()
         self._lib.nlos_render_args_init(ctypes.byref(a))
         _want(origin, torch.float32, "origin", 2); _want(normal, torch.float32, "normal", 2)
@@ -122,6 +122,12 @@ class TransientRenderer:
             _want(sensor, torch.float32, "sensor", 2); _want(sensor_normal, torch.float32, "sensor_normal", 2)
             assert sensor.shape == origin.shape and sensor_normal.shape == origin.shape, "sensor/sensor_normal need to be Lx3"
             a.sensor, a.sensor_normal = _dptr(sensor), _dptr(sensor_normal)
+        if jitter_weight is not None:
+            # SPAD jitter kernel (reference module `jitter`): f64 [K] or [K,1] device tensors
+            _want(jitter_weight, torch.float64, "jitter_weight"); _want(jitter_grad, torch.float64, "jitter_grad")
+            a.jitter_weight, a.jitter_grad = _dptr(jitter_weight), _dptr(jitter_grad)
+            a.jitter_offset, a.jitter_length = int(jitter_offset), int(jitter_weight.shape[0])
+            assert jitter_grad is None or jitter_grad.shape[0] == jitter_weight.shape[0], "jitter_grad needs one entry per tap"
         return a
 
     def _run(self, a, keep):

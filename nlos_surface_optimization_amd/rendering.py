@@ -11,11 +11,11 @@ opt.sigma_bin, opt.testing_flag, opt.loss_flag, opt.alpha_flag, opt.albedo_flag,
 opt.jitter, opt.normal; mesh.v, mesh.f, mesh.vn, mesh.alpha, mesh.albedo, mesh.f_affinity.
 
 Out of scope here: CGAL / El Topo remeshing,
-normal-smoothing regulariser, jitter kernel.
+normal-smoothing regulariser.
 """
 import numpy as np
 
-from . import embree_intersector, ggx, renderer
+from . import embree_intersector, ggx, jitter, renderer
 
 
 def _flag(opt, name, default=0):
@@ -40,8 +40,10 @@ def inverseRendering(mesh, data, weight, opt):
                                    gradient, data, weight, opt.bin_refine_resolution, opt.sigma_bin,
                                    opt.testing_flag)
     elif _flag(opt, 'jitter'):
-        raise NotImplementedError("SPAD jitter kernel (transient_rendering_cython/jitter) is a 'next' row "
-                                  "(SURVEY.md section 8f-1), not built yet")
+        jitter.renderStreamedGradient(opt.lighting, opt.lighting_normal, mesh.v, mesh.f, opt.sample_num, 0, ub,
+                                      opt.distance_resolution, opt.jitter_weight, opt.jitter_grad,
+                                      int(opt.jitter_offset), transient, pathlengths, gradient, data, weight,
+                                      opt.testing_flag)
     elif _flag(opt, 'albedo_flag'):
         albedo = np.ones(mesh.v.shape[0], dtype=np.float32, order='C') * mesh.albedo
         renderer.renderStreamedGradientWithAlbedo(opt.lighting, opt.lighting_normal, mesh.v, mesh.f, albedo,

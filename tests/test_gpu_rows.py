@@ -402,3 +402,53 @@ def test_nonconfocal_equals_confocal_when_sensor_is_laser(bunny):
     assert rel_l2(gnc.cpu().numpy(), gc.cpu().numpy()) <= 1e-5
     with pytest.raises(Exception):
         r.render_intensity(to, tn, tv, tf_, 20000, LB, UB, sensor=to.clone())       # rows X/A/GGX are confocal only
+
+
+# ------------------------------------------------------------------ jitter module
+def test_jitter_module_vs_oracle(bunny, orc):
+    """The reference's `jitter` module with its own measured kernel (jitter/jitter_info.mat) at its
+    own bin settings (jitter/test.py:41-45): forward rows and vertex gradient through the C ABI."""
+    import types
+    from nlos_surface_optimization_amd import jitter, rendering
+    v, f = bunny
+    j = np.load(os.path.join(GOLDEN, "jitter_info.npz"))
+    jw = np.ascontiguousarray(j["jitter_weight"], np.float64)
+    jg = np.ascontiguousarray(j["jitter_grad"], np.float64)
+    jo = int(j["jitter_offset"])
+    o, n = grid_sources(3, 0.2)
+    nb, res, ns = 1200, 0.0012, 20000
+    lb, ub = 0.0, nb * res
+    L = o.shape[0]
+    t_ref, _, p_ref = orc.render_jitter(o, n, v, f, ns, lb, float(np.float32(ub)), res, jw, jo, accel=1)
+    tr, path = np.zeros((L, nb)), np.zeros(nb)
+    jitter.renderStreamedTransient(o, n, v, f, ns, lb, ub, res, tr, path, jw, jo)
+    assert t_ref.sum() > 0
+    assert rel_l2(tr, t_ref) <= 1e-12 and np.array_equal(path, p_ref)
+    vn = vertex_normals(v, f)
+    t_vn, _, _ = orc.render_jitter(o, n, v, f, ns, lb, float(np.float32(ub)), res, jw, jo, vnormal=vn, accel=1)
+    tr2 = np.zeros((L, nb))
+    jitter.renderStreamedTransientShading(o, n, v, vn, f, ns, lb, ub, res, tr2, path, jw, jo)
+    assert rel_l2(tr2, t_vn) <= 1e-12
+    alb = (0.3 + 0.7 * np.random.RandomState(4).random_sample(v.shape[0])).astype(np.float32)
+    t_al, _, _ = orc.render_jitter(o, n, v, f, ns, lb, float(np.float32(ub)), res, jw, jo, albedo=alb, accel=1)
+    jitter.renderStreamedTransientwAlbedo(o, n, v, alb, f, ns, lb, ub, res, tr2, path, jw, jo)
+    assert rel_l2(tr2, t_al) <= 1e-12
+    # gradient (testing_flag 1: face normals, no normal term -- what exp_bunny runs)
+    rs = np.random.RandomState(8)
+    data = t_ref * (1 + 0.3 * rs.standard_normal(t_ref.shape))
+    w = 0.5 + rs.random_sample(t_ref.shape)
+    _, g_ref, _ = orc.render_jitter(o, n, v, f, ns, lb, float(np.float32(ub)), res, jw, jo, jitter_grad=jg,
+                                    data=data, weight=w, testing_flag=1, accel=1)
+    grad = np.zeros((v.shape[0], 3))
+    jitter.renderStreamedGradient(o, n, v, f, ns, lb, ub, res, jw, jg, jo, tr, path, grad, data, w, 1)
+    assert np.abs(g_ref).max() > 0
+    assert rel_l2(tr, t_ref) <= 1e-12
+    assert rel_l2(grad, g_ref) <= 1e-4
+    # facade: opt.jitter dispatch (exp_bunny/rendering.py:262-263)
+    opt = types.SimpleNamespace(lighting=o, lighting_normal=n, sample_num=ns, max_distance_bin=nb,
+                                distance_resolution=res, bin_refine_resolution=10, sigma_bin=1, testing_flag=1,
+                                loss_flag=0, alpha_flag=0, albedo_flag=0, jitter=1, jitter_weight=jw,
+                                jitter_grad=jg, jitter_offset=jo, normal="fn")
+    mesh = types.SimpleNamespace(v=v, f=f)
+    t3, g3, _ = rendering.inverseRendering(mesh, data, w, opt)
+    assert rel_l2(g3, g_ref) <= 1e-4 and rel_l2(t3, t_ref) <= 1e-12
