@@ -133,6 +133,19 @@ int nlos_nonconfocal_render_gradient(double *data, double *weight, float *laser,
         float resolution, double *transient, double *pathlengths, double *gradient,
         int refine_scale, int sigma_bin, int testing_flag, int loss_test);
 
+/* smoothed_transient/stratifiedStreamedGradientRenderer.h (streamed_render_normal_smoothing,
+ * streamed_render_curvature_grad; bodies :27-180).  curvature_grad [numVertices,3] is zeroed and
+ * filled; the reference returns the smoothing value, here it is written to *value_out.
+ * Per-vertex results are ACCUMULATED over the incident faces (the gradient of the formulas); the
+ * reference stores them with `=`, i.e. keeps whichever incident face wrote last --
+ * nlos_set_regulariser_overwrite(1) selects that behaviour deterministically (highest face index
+ * wins, the outcome of a serial run). */
+int nlos_streamed_render_normal_smoothing(float *vertices, int numVertices, int *triangles,
+        int numTriangles, int *face_affinity, double *curvature_grad, double *value_out);
+int nlos_streamed_render_curvature_grad(float *vertices, int numVertices, int *triangles,
+        int numTriangles, double *curvature_grad);
+void nlos_set_regulariser_overwrite(int overwrite);
+
 /* jitter/stratifiedStreamedTransientRenderer.h, jitter/stratifiedStreamedGradientRenderer.h:10
  * (the `jitter` extension module: measured SPAD jitter kernel instead of the Gaussian) */
 int nlos_jitter_streamed_render_transient(float *origin, int numSources, float *normal,
@@ -263,6 +276,12 @@ int nlos_render(nlos_ctx *ctx, const nlos_render_args *args, void *stream);
 int nlos_intersect(nlos_ctx *ctx, const float *origins, const float *dirs, int n_rays,
                    const float *vertices, int V, const int32_t *faces, int F,
                    float *out3, float *out1, void *stream);
+
+/* mesh regularisers on device pointers: face_affinity NULL -> area gradient (value may be NULL),
+ * else normal smoothing with *value (device, [1]) overwritten.  gradient [V,3] is overwritten. */
+int nlos_mesh_regulariser(nlos_ctx *ctx, const float *vertices, int V, const int32_t *faces, int F,
+                          const int32_t *face_affinity, double *gradient, double *value,
+                          int overwrite, void *stream);
 
 /* number of bins the reference computes in float32: ceil((ub-lb)/res) */
 int nlos_num_bins(float lower_bound, float upper_bound, float resolution);

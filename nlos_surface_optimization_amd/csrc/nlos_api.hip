@@ -80,6 +80,7 @@ struct nlos_ctx {
     int built_F = -1, built_V = -1;
     // render scratch
     DevBuf vis, diff, fine, taps, rows_tmp, grad_tmp, live;
+    DevBuf reg_normal, reg_area, reg_owner;
     int tap_refine = -1, tap_sigma = -1; float tap_res = -1.0f; int tap_kind = -1;
     // host-pointer path staging
     DevBuf io[16];
@@ -103,6 +104,7 @@ std::mutex g_mu;
 std::vector<nlos_ctx*> g_default_ctx;     // per device, for the host-pointer drop-ins
 uint64_t g_default_seed = 0;
 int g_default_device = 0;
+int g_reg_overwrite = 0;
 
 int get_default_ctx(nlos_ctx** out) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -261,6 +263,7 @@ int nlos_num_bins(float lb, float ub, float res) {
 
 void nlos_set_default_seed(uint64_t seed) { g_default_seed = seed; }
 void nlos_set_default_device(int device) { g_default_device = device; }
+void nlos_set_regulariser_overwrite(int overwrite) { g_reg_overwrite = overwrite ? 1 : 0; }
 
 int nlos_ctx_create(int device, nlos_ctx** out) {
     if (!out) return fail(NLOS_ERR_ARG, "nlos_ctx_create: out is NULL");
@@ -639,6 +642,28 @@ int nlos_intersect(nlos_ctx* c, const float* origins, const float* dirs, int n_r
     ia.sc = scene_view(c, F, V, nullptr, nullptr);
     ia.origins = origins; ia.dirs = dirs; ia.n = n_rays; ia.out3 = out3; ia.out1 = out1;
     nlos::launch_intersect(ia, st);
+    HIP_TRY(hipGetLastError());
+    return NLOS_OK;
+}
+
+int nlos_mesh_regulariser(nlos_ctx* c, const float* vertices, int V, const int32_t* faces, int F,
+                          const int32_t* face_affinity, double* gradient, double* value, int overwrite, void* stream) {
+    if (!c) return fail(NLOS_ERR_ARG, "nlos_mesh_regulariser: NULL ctx");
+    if (V <= 0 || F < 0 || !vertices || (F > 0 && !faces) || !gradient)
+        return fail(NLOS_ERR_ARG, "nlos_mesh_regulariser: bad mesh / gradient");
+    if (face_affinity && !value) return fail(NLOS_ERR_ARG, "nlos_mesh_regulariser: normal smoothing needs a value output");
+    DeviceGuard guard(c->device);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc = c->reg_normal.ensure(sizeof(double) * 3 * (size_t)(F > 0 ? F : 1));
+    if (!rc) rc = c->reg_area.ensure(sizeof(double) * (size_t)(F > 0 ? F : 1));
+    if (!rc && overwrite) rc = c->reg_owner.ensure(sizeof(int) * (size_t)V);
+    if (rc) return rc;
+    nlos::RegulariserArgs ra;
+    ra.vertices = vertices; ra.faces = faces; ra.affinity = face_affinity; ra.V = V; ra.F = F;
+    ra.normal = c->reg_normal.as<double>(); ra.area = c->reg_area.as<double>();
+    ra.owner = overwrite ? c->reg_owner.as<int>() : nullptr;
+    ra.gradient = gradient; ra.value = value; ra.overwrite = overwrite ? 1 : 0;
+    nlos::launch_regulariser(ra, st);
     HIP_TRY(hipGetLastError());
     return NLOS_OK;
 }
@@ -1079,6 +1104,53 @@ int nlos_barycentric_to_world_n(float* vertices, int num_vertices, int* triangle
         if (e != hipSuccess) return fail(NLOS_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
     }
     return NLOS_OK;
+}
+
+namespace {
+int host_regulariser(float* vertices, int numVertices, int* triangles, int numTriangles, int* face_affinity,
+                     double* curvature_grad, double* value_out) {
+    if (numVertices <= 0 || numTriangles < 0 || !vertices || (numTriangles > 0 && !triangles) || !curvature_grad)
+        return fail(NLOS_ERR_ARG, "mesh regulariser: bad arguments");
+    for (size_t i = 0; i < 3 * (size_t)numTriangles; ++i) {
+        if (triangles[i] < 0 || triangles[i] >= numVertices) return fail(NLOS_ERR_ARG, "face index out of range [0, numVertices)");
+        if (face_affinity && face_affinity[i] >= numTriangles) return fail(NLOS_ERR_ARG, "face_affinity entry out of range");
+    }
+    nlos_ctx* c = nullptr;
+    int rc = get_default_ctx(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceGuard guard(c->device);
+    HostCall hc;
+    hc.c = c;
+    const float* v = hc.up(vertices, 3 * (size_t)numVertices);
+    const int* f = hc.up(triangles, 3 * (size_t)numTriangles);
+    const int* aff = hc.up(face_affinity, 3 * (size_t)numTriangles);
+    double* g = hc.inout(curvature_grad, 3 * (size_t)numVertices, false);
+    double dummy = 0.0;
+    double* val = hc.inout(value_out ? value_out : &dummy, 1, false);
+    if (hc.rc) return hc.rc;
+    if (face_affinity && numTriangles > 0 && !aff) return fail(NLOS_ERR_HIP, "mesh regulariser: staging failed");
+    rc = nlos_mesh_regulariser(c, v, numVertices, f, numTriangles, aff, g, val, g_reg_overwrite, nullptr);
+    if (rc) return rc;
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail(NLOS_ERR_HIP, std::string("hipDeviceSynchronize: ") + hipGetErrorString(e));
+    for (auto& d : hc.downloads) {
+        e = hipMemcpy(d.first, d.second.first, d.second.second, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return fail(NLOS_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
+    }
+    return NLOS_OK;
+}
+}  // namespace
+
+int nlos_streamed_render_normal_smoothing(float* vertices, int numVertices, int* triangles, int numTriangles,
+                                          int* face_affinity, double* curvature_grad, double* value_out) {
+    if (!face_affinity || !value_out) return fail(NLOS_ERR_ARG, "normal smoothing: face_affinity / value_out is NULL");
+    return host_regulariser(vertices, numVertices, triangles, numTriangles, face_affinity, curvature_grad, value_out);
+}
+
+int nlos_streamed_render_curvature_grad(float* vertices, int numVertices, int* triangles, int numTriangles,
+                                        double* curvature_grad) {
+    return host_regulariser(vertices, numVertices, triangles, numTriangles, nullptr, curvature_grad, nullptr);
 }
 
 }  // extern "C"

@@ -139,6 +139,21 @@ struct IntersectArgs {
 };
 void launch_intersect(const IntersectArgs& a, hipStream_t stream);
 
+// mesh regularisers: area ("curvature") gradient and normal smoothing
+struct RegulariserArgs {
+    const float* vertices;   // [V,3]
+    const int32_t* faces;    // [F,3]
+    const int32_t* affinity; // [F,3] neighbour face per edge or -1; null = area gradient only
+    int V, F;
+    double* normal;          // [3F] scratch
+    double* area;            // [F]  scratch
+    int* owner;              // [V]  scratch (overwrite semantics only)
+    double* gradient;        // [V,3] zeroed by the launcher
+    double* value;           // [1]   zeroed by the launcher (may be null without affinity)
+    int overwrite;           // 0: accumulate over incident faces, 1: highest incident face wins
+};
+void launch_regulariser(const RegulariserArgs& a, hipStream_t stream);
+
 // small utilities
 void launch_zero_f64(double* p, size_t n, hipStream_t stream);
 void launch_bary_to_world(const float* V, const int32_t* F, const float* bary, int n, float* out,

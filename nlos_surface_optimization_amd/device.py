@@ -212,6 +212,21 @@ class TransientRenderer:
         self._run(a, (origin, normal, vertices, faces, vertex_normal))
         return intensity
 
+    def mesh_regulariser(self, vertices, faces, face_affinity=None, overwrite=False):
+        """SURVEY 8f-2 on device tensors: returns (value 0-dim f64 tensor | None, gradient [V,3] f64).
+        face_affinity None -> area ("curvature") gradient, else normal smoothing."""
+        _want(vertices, torch.float32, "vertices", 2); _want(faces, torch.int32, "faces", 2)
+        _want(face_affinity, torch.int32, "face_affinity", 2)
+        grad = torch.empty((vertices.shape[0], 3), dtype=torch.float64, device=self.device)
+        val = torch.zeros(1, dtype=torch.float64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            rc = self._lib.nlos_mesh_regulariser(self._h, _dptr(vertices), vertices.shape[0], _dptr(faces),
+                                                 faces.shape[0], _dptr(face_affinity), _dptr(grad), _dptr(val),
+                                                 1 if overwrite else 0, ctypes.c_void_p(stream))
+        _lib.check(rc, "nlos_mesh_regulariser")
+        return (val[0] if face_affinity is not None else None), grad
+
     def intersect(self, origins, directions, vertices, faces, short=False):
         """Row E on device tensors: [N,3] (primID,u,v; NaN u,v on a miss) or [N] primIDs."""
         _want(origins, torch.float32, "origins", 2); _want(directions, torch.float32, "directions", 2)

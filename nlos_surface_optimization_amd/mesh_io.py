@@ -78,3 +78,35 @@ def decimate_to(v, f, target_faces, tol=0.03, iters=40):
         else:
             hi_c = c
     return best
+
+
+def face_affinity(f):
+    """int32 [F,3]: for face i and its edge (f[i,k], f[i,(k+1)%3]) the face on the other side, or -1
+    on a boundary / non-manifold edge.  Stands in for the reference's cgal_api.face_affinity
+    (cgal_api/c_cgal_api.cpp:156-171, a CGAL half-edge walk); the regulariser only sums over the
+    up-to-three neighbours, so the slot order does not matter."""
+    f = np.asarray(f)
+    F = f.shape[0]
+    a = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], axis=0).astype(np.int64)
+    a.sort(axis=1)
+    key = a[:, 0] * (int(f.max()) + 1 if F else 1) + a[:, 1]
+    face = np.tile(np.arange(F), 3)
+    slot = np.repeat(np.arange(3), F)
+    order = np.argsort(key, kind="stable")
+    ks, fs, ss = key[order], face[order], slot[order]
+    out = -np.ones((F, 3), np.int32)
+    same_next = np.zeros(len(ks), bool)
+    same_next[:-1] = ks[1:] == ks[:-1]
+    same_prev = np.zeros(len(ks), bool)
+    same_prev[1:] = same_next[:-1]
+    # manifold interior edges appear exactly twice
+    first = same_next & ~same_prev
+    idx = np.nonzero(first)[0]
+    twice = np.ones(len(idx), bool)
+    nxt2 = idx + 2
+    ok = nxt2 < len(ks)
+    twice[ok] = ks[nxt2[ok]] != ks[idx[ok]]
+    idx = idx[twice]
+    out[fs[idx], ss[idx]] = fs[idx + 1]
+    out[fs[idx + 1], ss[idx + 1]] = fs[idx]
+    return np.ascontiguousarray(out)

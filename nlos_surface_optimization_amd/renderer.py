@@ -6,8 +6,9 @@ positional signatures, typed-array checks, `assert` shape validation, in-place
 outputs and `None` return (scalar-gradient variants return a Python float).  The
 work happens in libnlos_hip.so on an MI355X; nothing here computes on the CPU.
 
-Not part of the hot path ("next"): renderStreamedNormalSmoothing,
-renderStreamedCurvatureGradient.
+renderStreamedNormalSmoothing / renderStreamedCurvatureGradient accumulate
+the per-face terms over a vertex's incident faces; the reference stores them with `=` (last writer
+wins) -- `set_regulariser_overwrite(True)` selects that behaviour (highest incident face wins).
 """
 import ctypes
 import math
@@ -16,6 +17,40 @@ import numpy as np
 
 from . import _lib
 from ._check import f32, f64, i32, ptr
+
+
+def set_regulariser_overwrite(flag):
+    """False (default): accumulate per-vertex regulariser terms; True: the reference's `=` stores."""
+    _lib.lib().nlos_set_regulariser_overwrite(1 if flag else 0)
+
+
+def renderStreamedNormalSmoothing(vertices, faces, f_affinity, gradient):
+    """renderer.pyx:13-21 -> streamed_render_normal_smoothing; returns the smoothing value."""
+    f32(vertices, 2, "vertices"); i32(faces, 2, "faces"); i32(f_affinity, 2, "f_affinity"); f64(gradient, 2, "gradient")
+    assert vertices.shape[1] == 3, "vertices needs to be Vx3"
+    assert faces.shape[1] == 3, "faces needs to be Fx3"
+    assert f_affinity.shape[1] == 3, "face affinity needs to be Fx3"
+    assert f_affinity.shape[0] == faces.shape[0], "face affinity needs to be Fx3"
+    assert gradient.shape[0] == vertices.shape[0], "gradient dimension should be Vx3"
+    assert gradient.shape[1] == 3, "gradient dimension should be Vx3"
+    val = ctypes.c_double(0.0)
+    rc = _lib.lib().nlos_streamed_render_normal_smoothing(
+        ptr(vertices), vertices.shape[0], ptr(faces), faces.shape[0], ptr(f_affinity), ptr(gradient),
+        ctypes.cast(ctypes.byref(val), ctypes.c_void_p))
+    _lib.check(rc, "streamed_render_normal_smoothing")
+    return val.value
+
+
+def renderStreamedCurvatureGradient(vertices, faces, gradient):
+    """renderer.pyx:26-31 -> streamed_render_curvature_grad (gradient of the total surface area)."""
+    f32(vertices, 2, "vertices"); i32(faces, 2, "faces"); f64(gradient, 2, "gradient")
+    assert vertices.shape[1] == 3, "vertices needs to be Vx3"
+    assert faces.shape[1] == 3, "faces needs to be Fx3"
+    assert gradient.shape[0] == vertices.shape[0], "gradient dimension should be Vx3"
+    assert gradient.shape[1] == 3, "gradient dimension should be Vx3"
+    rc = _lib.lib().nlos_streamed_render_curvature_grad(
+        ptr(vertices), vertices.shape[0], ptr(faces), faces.shape[0], ptr(gradient))
+    _lib.check(rc, "streamed_render_curvature_grad")
 
 
 def _num_bins(lower_bound, upper_bound, resolution):

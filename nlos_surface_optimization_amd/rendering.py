@@ -10,8 +10,7 @@ opt.sample_num, opt.max_distance_bin, opt.distance_resolution, opt.bin_refine_re
 opt.sigma_bin, opt.testing_flag, opt.loss_flag, opt.alpha_flag, opt.albedo_flag,
 opt.jitter, opt.normal; mesh.v, mesh.f, mesh.vn, mesh.alpha, mesh.albedo, mesh.f_affinity.
 
-Out of scope here: CGAL / El Topo remeshing,
-normal-smoothing regulariser.
+Out of scope here: CGAL / El Topo remeshing.
 """
 import numpy as np
 
@@ -162,3 +161,18 @@ def create_weighting_function(data, gamma=1):
     weight = weight / total
     weight *= data.shape[0] * data.shape[1]
     return weight
+
+
+def renderStreamedNormalSmoothing(mesh):
+    """exp_bunny/rendering.py:298-301; mesh.f_affinity is the int32 [F,3] neighbour table
+    (cgal_api.face_affinity in the reference, mesh_io.face_affinity here)."""
+    gradient = np.zeros(mesh.v.shape, dtype=np.double, order='C')
+    val = renderer.renderStreamedNormalSmoothing(mesh.v, mesh.f, mesh.f_affinity, gradient)
+    return val, gradient
+
+
+def renderStreamedCurvatureGradient(mesh):
+    """exp_bunny/rendering.py:303-306."""
+    gradient = np.zeros(mesh.v.shape, dtype=np.double, order='C')
+    renderer.renderStreamedCurvatureGradient(mesh.v, mesh.f, gradient)
+    return gradient

@@ -170,6 +170,19 @@ def render_gradient(origin, normal, v, f, num_sample, lb, ub, res, data, weight,
     return transient, gradient, path
 
 
+def mesh_regulariser(v, f, affinity=None, overwrite=False):
+    """Returns (value, gradient [V,3]); affinity None -> area ("curvature") gradient, value 0."""
+    v, f = _f32(v), _i32(f)
+    aff = None if affinity is None else _i32(affinity)
+    grad = np.zeros((v.shape[0], 3), dtype=np.float64)
+    fn = lib().nlos_oracle_mesh_regulariser
+    fn.restype = ctypes.c_double
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                   ctypes.c_void_p, ctypes.c_int]
+    val = fn(_p(v), v.shape[0], _p(f), f.shape[0], _p(aff), _p(grad), 1 if overwrite else 0)
+    return float(val), grad
+
+
 def render_jitter(origin, normal, v, f, num_sample, lb, ub, res, jitter_weight, jitter_offset,
                   jitter_grad=None, data=None, weight=None, testing_flag=1, vnormal=None, albedo=None,
                   gradient=None, **kw):

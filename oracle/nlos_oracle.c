@@ -1072,6 +1072,78 @@ int nlos_oracle_render_gradient_v1(const double *data, const float *origin, int 
     return 0;
 }
 
+/* -------------------------------------------------------------- regularisers */
+/* SMO/stratifiedStreamedGradientRenderer.cpp:27-180.
+ * curvature_grad: per face g_j = cross(n, e_j / 2) = d(area)/d v_j           (:27-56, :159-180)
+ * normal smoothing: value = sum_f A_f (1 - nbar_f . n_f), nbar_f = normalise(A_f n_f + sum_nbr A_g n_g),
+ *                   per face g_j = cross(n_f - nbar_f, e_j / 2)              (:58-156)
+ * The reference stores the per-vertex result with `=` and (in normal smoothing) lets every TBB
+ * thread write thread 0's buffer, so its output is "whichever incident face wrote last".
+ * overwrite = 0 (default here): accumulate over the incident faces -- the gradient the formulas
+ * describe.  overwrite = 1: the incident face with the highest index wins -- what a serial run of
+ * the reference produces.  Degenerate faces (area 0) are skipped in both roles, and so is a face
+ * whose area-weighted neighbourhood normal cancels (shorter than 1e-3 of the summed areas: 0/0 or
+ * rounding noise in the reference). */
+static void face_normal_area(const float *V, const int32_t *F, int f, v3 *n, float *area, v3 *p) {
+    p[0] = ld3(V + 3 * (size_t)F[3 * f]);
+    p[1] = ld3(V + 3 * (size_t)F[3 * f + 1]);
+    p[2] = ld3(V + 3 * (size_t)F[3 * f + 2]);
+    v3 nr = cross3(sub3(p[1], p[0]), sub3(p[2], p[0]));
+    *area = sqrtf(dot3(nr, nr)) / 2;
+    *n = scl3(nr, 1.0f / (2 * *area));
+}
+
+double nlos_oracle_mesh_regulariser(const float *V, int nV, const int32_t *F, int nF,
+                                    const int32_t *affinity, double *gradient, int overwrite) {
+    double *normal = (double *)malloc(sizeof(double) * 3 * (size_t)nF);
+    double *area = (double *)malloc(sizeof(double) * (size_t)nF);
+    double value = 0;
+    v3 p[3];
+    for (int f = 0; f < nF; ++f) {
+        v3 n; float a;
+        face_normal_area(V, F, f, &n, &a, p);
+        area[f] = a;
+        normal[3 * f] = n.x; normal[3 * f + 1] = n.y; normal[3 * f + 2] = n.z;
+    }
+    memset(gradient, 0, sizeof(double) * 3 * (size_t)nV);
+    for (int f = 0; f < nF; ++f) {          /* ascending order: "=" keeps the highest incident face */
+        if (!(area[f] > 0)) continue;
+        v3 fn = mk((float)normal[3 * f], (float)normal[3 * f + 1], (float)normal[3 * f + 2]);
+        v3 d = fn;
+        if (affinity) {
+            v3 n = scl3(fn, (float)area[f]);
+            float wsum = (float)area[f];
+            for (int i = 0; i < 3; ++i) {
+                int g = affinity[3 * f + i];
+                if (g < 0 || !(area[g] > 0)) continue;
+                v3 n1 = mk((float)normal[3 * g], (float)normal[3 * g + 1], (float)normal[3 * g + 2]);
+                n = add3(n, scl3(n1, (float)area[g]));
+                wsum += (float)area[g];
+            }
+            float len = sqrtf(dot3(n, n));
+            if (!(len > 1e-3f * wsum)) {        /* neighbourhood normals cancel (0/0 or noise in the reference) */
+                if (overwrite)                   /* the face still "writes last": zeros */
+                    for (int j = 0; j < 3; ++j) memset(gradient + 3 * (size_t)F[3 * f + j], 0, 3 * sizeof(double));
+                continue;
+            }
+            n = scl3(n, 1.0f / len);
+            value += area[f] * (1 - dot3(n, fn));
+            d = sub3(fn, n);
+        }
+        v3 nn; float aa;
+        face_normal_area(V, F, f, &nn, &aa, p);
+        const v3 e[3] = {sub3(p[2], p[1]), sub3(p[0], p[2]), sub3(p[1], p[0])};
+        for (int j = 0; j < 3; ++j) {
+            v3 g = cross3(d, scl3(e[j], 0.5f));
+            double *o = gradient + 3 * (size_t)F[3 * f + j];
+            if (overwrite) { o[0] = g.x; o[1] = g.y; o[2] = g.z; }
+            else { o[0] += g.x; o[1] += g.y; o[2] += g.z; }
+        }
+    }
+    free(normal); free(area);
+    return value;
+}
+
 /* ------------------------------------------------------------------- jitter */
 /* SPAD jitter variant, transient_rendering_cython/jitter/ ("JIT"):
  * forward = plain histogram convolved with the measured jitter kernel
