@@ -283,6 +283,27 @@ int nlos_mesh_regulariser(nlos_ctx *ctx, const float *vertices, int V, const int
                           const int32_t *face_affinity, double *gradient, double *value,
                           int overwrite, void *stream);
 
+/* ---- the steps that follow the render in every loop of the reference, on device pointers ----
+ * Adam_Modified (exp_bunny/adam_modified.py:62-107): Adam with ONE denominator per row, the mean of
+ * sqrt(exp_avg_sq) + eps over the row's columns.  params / exp_avg / exp_avg_sq (/ max_exp_avg_sq
+ * for amsgrad, else NULL) are float32 [rows, cols]; the gradient is the renderer's float64 output
+ * (grad_f64, narrowed like `torch.from_numpy(grad).float()`, exp_bunny/test.py:212-213) or a float32
+ * array (grad_f32); exactly one of the two.  step is the 1-based step count.  row_mask (uint8
+ * [rows], NULL = all) leaves rows with 0 untouched: the reference keeps two parameter groups with
+ * different learning rates over disjoint vertex sets (exp_bunny/test.py:56-60).  cols <= 8. */
+int nlos_adam_modified_step(nlos_ctx *ctx, float *params, const double *grad_f64, const float *grad_f32,
+                            float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
+                            const uint8_t *row_mask, int rows, int cols, int step, double lr,
+                            double beta1, double beta2, double eps, double weight_decay, void *stream);
+/* create_weighting_function (exp_bunny/rendering.py:208-217): weight = (data/max(data) + 0.1)^gamma,
+ * rescaled to sum to rows*cols.  data, weight: float64 [rows, cols]. */
+int nlos_create_weighting(nlos_ctx *ctx, const double *data, int rows, int cols, double gamma,
+                          double *weight, void *stream);
+/* L1 term of evaluate_loss_with_* (exp_bunny/rendering.py:360-364):
+ * out[0] = sum weight * (transient - data)^2 / rows  (weight NULL -> 1). */
+int nlos_weighted_l2(nlos_ctx *ctx, const double *transient, const double *data, const double *weight,
+                     int rows, int cols, double *out, void *stream);
+
 /* number of bins the reference computes in float32: ceil((ub-lb)/res) */
 int nlos_num_bins(float lower_bound, float upper_bound, float resolution);
 

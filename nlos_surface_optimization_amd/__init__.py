@@ -15,12 +15,12 @@ from . import _lib  # noqa: F401
 from . import embree_intersector, ggx, jitter, renderer, renderer_v1, rendering, rendering_v1  # noqa: F401
 
 __all__ = ["renderer", "renderer_v1", "ggx", "jitter", "embree_intersector", "rendering", "rendering_v1",
-           "device", "dist", "mesh_io"]
+           "device", "dist", "mesh_io", "adam_modified"]
 
 
 def __getattr__(name):
     # torch-dependent submodules are imported lazily
-    if name in ("device", "dist", "mesh_io"):
+    if name in ("device", "dist", "mesh_io", "adam_modified"):
         import importlib
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

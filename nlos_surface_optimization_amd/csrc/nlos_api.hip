@@ -646,6 +646,50 @@ int nlos_intersect(nlos_ctx* c, const float* origins, const float* dirs, int n_r
     return NLOS_OK;
 }
 
+int nlos_adam_modified_step(nlos_ctx* c, float* params, const double* grad_f64, const float* grad_f32, float* exp_avg,
+                            float* exp_avg_sq, float* max_exp_avg_sq, const uint8_t* row_mask, int rows, int cols,
+                            int step, double lr, double beta1, double beta2, double eps, double weight_decay,
+                            void* stream) {
+    if (!c) return fail(NLOS_ERR_ARG, "nlos_adam_modified_step: NULL ctx");
+    if (rows < 0 || cols < 1 || cols > 8) return fail(NLOS_ERR_ARG, "nlos_adam_modified_step: need rows >= 0 and 1 <= cols <= 8");
+    if (rows > 0 && (!params || !exp_avg || !exp_avg_sq)) return fail(NLOS_ERR_ARG, "nlos_adam_modified_step: NULL state");
+    if ((grad_f64 != nullptr) == (grad_f32 != nullptr)) return fail(NLOS_ERR_ARG, "nlos_adam_modified_step: pass exactly one of grad_f64 / grad_f32");
+    if (step < 1) return fail(NLOS_ERR_ARG, "nlos_adam_modified_step: step counts from 1");
+    if (!(lr >= 0.0) || !(eps >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0))
+        return fail(NLOS_ERR_ARG, "nlos_adam_modified_step: invalid lr / eps / betas");      // adam_modified.py:33-40
+    DeviceGuard guard(c->device);
+    nlos::AdamArgs a;
+    a.params = params; a.grad64 = grad_f64; a.grad32 = grad_f32; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq;
+    a.max_exp_avg_sq = max_exp_avg_sq; a.row_mask = row_mask; a.rows = rows; a.cols = cols;
+    a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.eps = (float)eps; a.weight_decay = (float)weight_decay;
+    a.one_minus_beta1 = (float)(1 - beta1); a.one_minus_beta2 = (float)(1 - beta2);
+    // adam_modified.py:102-104, python float (double) arithmetic
+    const double bc1 = 1 - std::pow(beta1, step), bc2 = 1 - std::pow(beta2, step);
+    a.step_size = (float)(lr * std::sqrt(bc2) / bc1);
+    nlos::launch_adam_modified(a, reinterpret_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return NLOS_OK;
+}
+
+int nlos_create_weighting(nlos_ctx* c, const double* data, int rows, int cols, double gamma, double* weight, void* stream) {
+    if (!c) return fail(NLOS_ERR_ARG, "nlos_create_weighting: NULL ctx");
+    if (rows < 0 || cols < 0 || ((size_t)rows * cols > 0 && (!data || !weight))) return fail(NLOS_ERR_ARG, "nlos_create_weighting: bad arguments");
+    DeviceGuard guard(c->device);
+    nlos::launch_weighting(data, (size_t)rows * cols, gamma, weight, reinterpret_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return NLOS_OK;
+}
+
+int nlos_weighted_l2(nlos_ctx* c, const double* transient, const double* data, const double* weight, int rows, int cols,
+                     double* out, void* stream) {
+    if (!c) return fail(NLOS_ERR_ARG, "nlos_weighted_l2: NULL ctx");
+    if (rows < 0 || cols < 0 || !out || ((size_t)rows * cols > 0 && (!transient || !data))) return fail(NLOS_ERR_ARG, "nlos_weighted_l2: bad arguments");
+    DeviceGuard guard(c->device);
+    nlos::launch_weighted_l2(transient, data, weight, (size_t)rows * cols, rows, out, reinterpret_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return NLOS_OK;
+}
+
 int nlos_mesh_regulariser(nlos_ctx* c, const float* vertices, int V, const int32_t* faces, int F,
                           const int32_t* face_affinity, double* gradient, double* value, int overwrite, void* stream) {
     if (!c) return fail(NLOS_ERR_ARG, "nlos_mesh_regulariser: NULL ctx");

@@ -154,6 +154,27 @@ struct RegulariserArgs {
 };
 void launch_regulariser(const RegulariserArgs& a, hipStream_t stream);
 
+// optimiser-side steps that follow the render in every loop of the reference
+struct AdamArgs {
+    float* params;           // [rows, cols] updated in place
+    const double* grad64;    // [rows, cols] (renderer output) or null
+    const float* grad32;     // [rows, cols] or null (exactly one of the two)
+    float* exp_avg;          // [rows, cols]
+    float* exp_avg_sq;       // [rows, cols]
+    float* max_exp_avg_sq;   // [rows, cols] (amsgrad) or null
+    const uint8_t* row_mask; // [rows] rows with 0 are left untouched; null = all rows
+    int rows, cols;
+    float beta1, beta2, eps, weight_decay;
+    float one_minus_beta1, one_minus_beta2;
+    float step_size;         // lr * sqrt(1 - beta2^t) / (1 - beta1^t), evaluated in double on the host
+};
+void launch_adam_modified(const AdamArgs& a, hipStream_t stream);
+// weight = ((data / max(data) + 0.1)^gamma), rescaled to sum to n (exp_bunny/rendering.py:208-217)
+void launch_weighting(const double* data, size_t n, double gamma, double* weight, hipStream_t stream);
+// out[0] = sum weight * (transient - data)^2 / rows (exp_bunny/rendering.py:360-364, L1)
+void launch_weighted_l2(const double* transient, const double* data, const double* weight, size_t n, int rows,
+                        double* out, hipStream_t stream);
+
 // small utilities
 void launch_zero_f64(double* p, size_t n, hipStream_t stream);
 void launch_bary_to_world(const float* V, const int32_t* F, const float* bary, int n, float* out,

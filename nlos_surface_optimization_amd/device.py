@@ -227,6 +227,30 @@ class TransientRenderer:
         _lib.check(rc, "nlos_mesh_regulariser")
         return (val[0] if face_affinity is not None else None), grad
 
+    def create_weighting_function(self, data, gamma=1.0):
+        """exp_bunny/rendering.py:208-217 on a device tensor: (data/max + 0.1)^gamma, rescaled to sum to data.numel()."""
+        _want(data, torch.float64, "data", 2)
+        weight = torch.empty_like(data)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            rc = self._lib.nlos_create_weighting(self._h, _dptr(data), data.shape[0], data.shape[1], float(gamma),
+                                                 _dptr(weight), ctypes.c_void_p(stream))
+        _lib.check(rc, "nlos_create_weighting")
+        return weight
+
+    def weighted_l2(self, transient, data, weight=None):
+        """L1 term of evaluate_loss_with_* (exp_bunny/rendering.py:360-364): sum w (T - data)^2 / rows, 0-dim f64."""
+        _want(transient, torch.float64, "transient", 2); _want(data, torch.float64, "data", 2)
+        _want(weight, torch.float64, "weight", 2)
+        assert transient.shape == data.shape and (weight is None or weight.shape == data.shape), "shapes should be LxB"
+        out = torch.empty(1, dtype=torch.float64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            rc = self._lib.nlos_weighted_l2(self._h, _dptr(transient), _dptr(data), _dptr(weight), data.shape[0],
+                                            data.shape[1], _dptr(out), ctypes.c_void_p(stream))
+        _lib.check(rc, "nlos_weighted_l2")
+        return out[0]
+
     def intersect(self, origins, directions, vertices, faces, short=False):
         """Row E on device tensors: [N,3] (primID,u,v; NaN u,v on a miss) or [N] primIDs."""
         _want(origins, torch.float32, "origins", 2); _want(directions, torch.float32, "directions", 2)

@@ -176,3 +176,25 @@ def renderStreamedCurvatureGradient(mesh):
     gradient = np.zeros(mesh.v.shape, dtype=np.double, order='C')
     renderer.renderStreamedCurvatureGradient(mesh.v, mesh.f, gradient)
     return gradient
+
+
+def create_weighting_function(data, gamma=1):
+    """exp_bunny/rendering.py:208-217 (host numpy, as in the reference; device twin:
+    device.TransientRenderer.create_weighting_function)."""
+    eps = 0.1
+    i_max = np.max(data)
+    normalized_data = data / i_max
+    weight = (normalized_data + eps) ** gamma
+    total = np.sum(weight)
+    weight = weight / total
+    weight *= data.shape[0] * data.shape[1]
+    return weight
+
+
+def evaluate_loss_with_normal_smoothness(gt_transient, weight, transient, smoothing_val, mesh, render_opt):
+    """exp_bunny/rendering.py:360-367 -> (L1 + smooth_weight * smoothing_val, L1)."""
+    difference = transient - gt_transient
+    difference = difference * np.sqrt(weight)
+    L1 = np.linalg.norm(difference) ** 2 / difference.shape[0]
+    L2 = render_opt.smooth_weight * smoothing_val
+    return L1 + L2, L1

@@ -12,6 +12,8 @@ Reads /root/reference (read-only, absent on the GPU box) and writes DATA only:
   pyref_angular_nc.npz  the same prototype with lighting != sensor (row N, non-confocal pairs), incl. a
                       blocker that hides paths from one end point only
   jitter_info.npz     jitter/jitter_info.mat (the reference's measured SPAD jitter kernel) as npz
+  adam_modified.npz   parameter trajectories of the reference's own optimiser class
+                      (exp_bunny/adam_modified.py, imported and run on CPU) on fixed gradients
   oracle_cfg1.npz     oracle transient + gradient for BASELINE config 1 (regression pin)
   oracle_bunny16.npz  oracle transient + gradient, bunny_5k, 16 sources (regression pin)
   ggx_table.npz       oracle GGX eval / eval_adiff / eval_nwdiff over an (alpha, n.w) grid
@@ -182,6 +184,35 @@ def make_jitter_info():
                         jitter_time=j["jitter_time"])
 
 
+def make_adam_modified():
+    """Trajectory of the reference's own optimiser (exp_bunny/adam_modified.py, imported, on CPU):
+    fixed float64 gradients narrowed to float32 as exp_bunny/test.py:212-213 does."""
+    import warnings
+    import torch
+    sys.path.insert(0, os.path.join(REF, "transient_rendering_cython/exp_bunny"))
+    from adam_modified import Adam_Modified  # noqa: E402  (the reference class)
+    rs = np.random.RandomState(21)
+    p0 = rs.standard_normal((257, 3)).astype(np.float32) * 0.1
+    grads = rs.standard_normal((6, 257, 3)) * np.logspace(-6, -2, 257)[None, :, None]
+    out = {"p0": p0, "grads": grads}
+    for name, kw in (("plain", dict(lr=1e-4 / 3)), ("amsgrad_wd", dict(lr=2e-3, amsgrad=True, weight_decay=0.01,
+                                                                       betas=(0.8, 0.99), eps=1e-6))):
+        p = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+        opt = Adam_Modified([p], **kw)
+        traj = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for g in grads:
+                p.grad = torch.from_numpy(g).float()
+                opt.step()
+                traj.append(p.data.numpy().copy())
+        out[name + "_traj"] = np.stack(traj)
+        out[name + "_kw"] = np.array([kw["lr"], kw.get("betas", (0.9, 0.999))[0], kw.get("betas", (0.9, 0.999))[1],
+                                      kw.get("eps", 1e-8), kw.get("weight_decay", 0.0), float(kw.get("amsgrad", False))])
+    np.savez_compressed(os.path.join(HERE, "adam_modified.npz"), **out)
+    print("adam_modified", out["plain_traj"].shape)
+
+
 def make_oracle_cfg1():
     v, f, origin, normal = cfg1()
     lb, ub, res = 0.0, 2.0, 2.0 ** -5
@@ -235,6 +266,7 @@ if __name__ == "__main__":
     make_pyref()
     make_pyref_nc()
     make_jitter_info()
+    make_adam_modified()
     make_oracle_cfg1()
     make_oracle_bunny(bv, bf)
     make_ggx_table()
