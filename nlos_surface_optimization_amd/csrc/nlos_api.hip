@@ -618,9 +618,8 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
                 ga.diff = transient;   // unused by mode 3; any valid [L,T] buffer
                 break;
         }
-        // LDS: diff row + tap tables + 3V accumulator + live-face list (4.2 B per face)
-        ga.lds_grad = ((ga.mode == 0 || ga.mode == 4) && (3 * (size_t)nV + (size_t)T + 3 * (size_t)K + 2) * sizeof(double) +
-                                           5 * (size_t)nF + 128 <= (size_t)nlos::kGradLdsBudget) ? 1 : 0;
+        ga.lds_grad = 1;          // allowed; launch_gradient decides from the LDS the mesh needs
+        ga.compact = 0;
         nlos::launch_gradient(ga, st);
     }
     mark(c, 4, st);

@@ -124,7 +124,8 @@ struct GradientArgs {
                              //   K = jitter_length, two_rs = jitter_offset; delta/p0/p1 unused)
     int vertex_num;
     double* out;             // gradient [V,3] | scalar [1] | [T,3]
-    int lds_grad;            // 1: per-workgroup LDS accumulator (3V doubles) fits
+    int lds_grad;            // in: 1 = per-workgroup LDS accumulator allowed; the launcher clears it when 3V doubles do not fit
+    int compact;             // set by the launcher: 1 = compacted u16 list of faces with accepted samples in LDS
 };
 void launch_gradient(const GradientArgs& a, hipStream_t stream);
 
@@ -181,6 +182,6 @@ void launch_bary_to_world(const float* V, const int32_t* F, const float* bary, i
                           hipStream_t stream);
 
 // LDS budget the gradient kernel may use for its accumulator (bytes)
-constexpr int kGradLdsBudget = 96 * 1024;
+constexpr int kGradLdsBudget = 150 * 1024;
 
 }  // namespace nlos

@@ -1167,7 +1167,7 @@ __global__ __launch_bounds__(512, 4) void k_gradient(GradientArgs a) {
     double* s_grad = s_p1 + K + 1;          // [3V] when lds_grad
     unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(s_grad + (((MODE == 0 || MODE == 4) && a.lds_grad) ? 3 * V : 0));
     uint32_t* s_base = reinterpret_cast<uint32_t*>(s_mask + nblocks);              // [nblocks+1]
-    uint32_t* s_live = s_base + ((nblocks + 2) & ~1);                               // [F] sorted face slots
+    uint16_t* s_live = reinterpret_cast<uint16_t*>(s_base + ((nblocks + 2) & ~1));   // [F] sorted face slots (compact only)
     const int spt = a.sp.spt;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int Ltot = a.src.total_sources > 0 ? a.src.total_sources : a.src.L;
@@ -1221,10 +1221,11 @@ __global__ __launch_bounds__(512, 4) void k_gradient(GradientArgs a) {
         __syncthreads();
         for (int b = wave; b < nblocks; b += nwaves) {
             const unsigned long long m = s_mask[b];
-            if ((m >> lane) & 1ull) s_live[s_base[b] + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)((b << 6) + lane);
+            if (a.compact && ((m >> lane) & 1ull))
+                s_live[s_base[b] + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((b << 6) + lane);
         }
         __syncthreads();
-        const int n_live = (int)s_base[nblocks];
+        const int n_live = a.compact ? (int)s_base[nblocks] : F;
         const int live_blocks = (n_live + 63) >> 6;
         const V3 o = ld3(a.src.origin + 3 * (size_t)l);
         const V3 on = ld3(a.src.normal + 3 * (size_t)l);
@@ -1237,7 +1238,7 @@ __global__ __launch_bounds__(512, 4) void k_gradient(GradientArgs a) {
             if (b >= live_blocks) break;
             const int li = (b << 6) + lane;
             if (li >= n_live) continue;
-            const int j = (int)s_live[li];
+            const int j = a.compact ? (int)s_live[li] : li;
             const uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
             const Face f = load_face(a.sc.facerec, j);
             if (MODE == 3 && f.i0 != a.vertex_num && f.i1 != a.vertex_num && f.i2 != a.vertex_num) continue;
@@ -1536,13 +1537,19 @@ void launch_residual(const ResidualArgs& a, hipStream_t stream) {
                            a.w_width);
 }
 
-void launch_gradient(const GradientArgs& a, hipStream_t stream) {
-    if (a.src.L <= 0) return;
-    size_t lds = 8 + ((size_t)a.sp.nbins + 3 * (size_t)a.K + 2) * sizeof(double);
-    if ((a.mode == 0 || a.mode == 4) && a.lds_grad) lds += 3 * (size_t)a.sc.V * sizeof(double);
+void launch_gradient(const GradientArgs& a_in, hipStream_t stream) {
+    if (a_in.src.L <= 0) return;
+    GradientArgs a = a_in;
     const size_t nblk = ((size_t)a.sc.F + 63) / 64;
-    lds += nblk * 8 + ((nblk + 2) & ~(size_t)1) * 4 + (size_t)a.sc.F * 4;
-    // persistent workgroups: as many as can be co-resident (512 threads each)
+    size_t lds = 8 + ((size_t)a.sp.nbins + 3 * (size_t)a.K + 2) * sizeof(double) + nblk * 8 + ((nblk + 2) & ~(size_t)1) * 4;
+    // compacted list of the faces with accepted samples (u16): skipped for meshes it cannot index / hold
+    a.compact = (a.sc.F <= 65535 && lds + 2 * (size_t)a.sc.F + 16 <= 64 * 1024) ? 1 : 0;
+    if (a.compact) lds += (2 * (size_t)a.sc.F + 15) & ~(size_t)15;
+    // per-workgroup 3V-double accumulator while it fits beside the rest (one workgroup per CU at worst)
+    const size_t acc = 3 * (size_t)a.sc.V * sizeof(double);
+    a.lds_grad = ((a.mode == 0 || a.mode == 4) && a_in.lds_grad && lds + acc <= 150 * 1024) ? 1 : 0;
+    if (a.lds_grad) lds += acc;
+    // persistent workgroups: as many as can be co-resident (512 threads each, <= 128 VGPRs -> 4 per CU)
     int per_cu = (int)(160 * 1024 / (lds + 64));
     if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;
