@@ -482,7 +482,6 @@ __global__ __launch_bounds__(256) void k_forward_nc(ForwardArgs a, int rows_in_l
 // fall back to the stackless BVH traversal.
 struct GridView {
     float gx0, gy0, inv_cw, inv_ch;   // cell = floor((m - g0) * inv_c)
-    float inv_qx, inv_qy;             // quantised coordinate = floor((m - g0) * inv_q), 256 levels
     float z0, inv_qz;                 // quantised depth = floor((z - z0) * inv_qz), zmax levels over the scene
     int ib, zmax;                     // entry = index (ib bits) | x0:3 x1:3 y0:3 y1:3 | depth (32-12-ib bits)
     int R;
@@ -506,18 +505,27 @@ __device__ __forceinline__ Proj2 project_tri(V3 o, V3 p0, V3 p1, V3 p2) {
     return q;
 }
 
-// Cell-list entry (32 bit, LDS): triangle index in the low `ib` bits, then the triangle's projected
-// bounding box clipped to THIS cell in eighths of the cell (x0, x1, y0, y1: 3 bits each, rounded
-// outwards by one level), then its smallest depth quantised downwards over the scene's depth range.
-// One LDS read per candidate gives everything the filter needs.
+// Cell-list entry (32 bit, LDS), most significant first:
+//   [31:25] smallest depth of the triangle, quantised downwards to 128 levels over the scene's depth range
+//   [24:19] y mask, [18:13] x mask: which sixths of THIS cell the triangle's projected bounding box touches
+//   [12:0]  index of the triangle (Morton order); the grid path is limited to F <= 8191
+// A ray carries  rlim = (its own hit depth level << 25) | 0x1FFFFFF  and  rmask = its sub-cell bit in
+// both masks; a candidate survives iff  w <= rlim  (not entirely behind the hit),  (w & rmask) == rmask
+// (the slope point is inside the box) and it is not the ray's own face: three compares on one LDS word.
 struct BBoxF { float x0, x1, y0, y1; };
+constexpr int kSub = 6;          // sub-cell levels per axis
+constexpr int kIdxBits = 13;
 
 __device__ __forceinline__ uint32_t make_entry(const GridView& g, const BBoxF& bb, int xx, int yy, uint32_t zq, int k) {
-    const float fx0 = ((bb.x0 - g.gx0) * g.inv_cw - (float)xx) * 8.0f, fx1 = ((bb.x1 - g.gx0) * g.inv_cw - (float)xx) * 8.0f;
-    const float fy0 = ((bb.y0 - g.gy0) * g.inv_ch - (float)yy) * 8.0f, fy1 = ((bb.y1 - g.gy0) * g.inv_ch - (float)yy) * 8.0f;
-    const uint32_t a0 = (uint32_t)min(max((int)floorf(fx0) - 1, 0), 7), a1 = (uint32_t)min(max((int)floorf(fx1) + 1, 0), 7);
-    const uint32_t b0 = (uint32_t)min(max((int)floorf(fy0) - 1, 0), 7), b1 = (uint32_t)min(max((int)floorf(fy1) + 1, 0), 7);
-    return (uint32_t)k | (((a0) | (a1 << 3) | (b0 << 6) | (b1 << 9) | (zq << 12)) << g.ib);
+    // the box is widened by 0.02 sub-cells: > 50x the fp32 error of the two projections (rcp, 1 ulp)
+    const float fx0 = ((bb.x0 - g.gx0) * g.inv_cw - (float)xx) * (float)kSub - 0.02f;
+    const float fx1 = ((bb.x1 - g.gx0) * g.inv_cw - (float)xx) * (float)kSub + 0.02f;
+    const float fy0 = ((bb.y0 - g.gy0) * g.inv_ch - (float)yy) * (float)kSub - 0.02f;
+    const float fy1 = ((bb.y1 - g.gy0) * g.inv_ch - (float)yy) * (float)kSub + 0.02f;
+    const int a0 = min(max((int)floorf(fx0), 0), kSub - 1), a1 = min(max((int)floorf(fx1), 0), kSub - 1);
+    const int b0 = min(max((int)floorf(fy0), 0), kSub - 1), b1 = min(max((int)floorf(fy1), 0), kSub - 1);
+    const uint32_t xm = (2u << a1) - (1u << a0), ym = (2u << b1) - (1u << b0);
+    return (zq << 25) | (ym << 19) | (xm << 13) | (uint32_t)k;
 }
 
 // conservative rasterisation of a projected triangle: fn(xx, yy) for every overlapped cell
@@ -610,10 +618,8 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
         g.gy0 = gy0 - 1e-3f * wy;
         g.inv_cw = (float)R / (wx * 1.002f);
         g.inv_ch = (float)R / (wy * 1.002f);
-        g.inv_qx = 256.0f / (wx * 1.002f);
-        g.inv_qy = 256.0f / (wy * 1.002f);
-        g.ib = F <= 8192 ? 13 : 16;
-        g.zmax = (1 << (20 - g.ib)) - 1;
+        g.ib = kIdxBits;
+        g.zmax = 127;
         g.z0 = zr0;
         g.inv_qz = (float)g.zmax / fmaxf(zr1 - zr0, 1e-12f);
     }
@@ -831,16 +837,18 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
                 ok = !occluded(a.sc.nodes, a.sc.n_nodes, a.sc.tris, a.sc.face_id, o, gg.dir, t_self, j, f.fid);
 
             // ---- stage 1 + 2 (wave-synchronous; every lane takes part) ----
-            uint32_t e = 0, e1 = 0, sx = 0, sy = 0, rq = 0;
+            uint32_t e = 0, e1 = 0, rmask = 0, rlim = 0;
             if (grid_ray) {
                 const float iz = __builtin_amdgcn_rcpf(gg.dir.z);   // lookups only: 1-ulp rcp is fine
                 const float ux = (gg.dir.x * iz - g.gx0) * g.inv_cw, uy = (gg.dir.y * iz - g.gy0) * g.inv_ch;
                 const int cxx = min(max((int)floorf(ux), 0), R - 1), cyy = min(max((int)floorf(uy), 0), R - 1);
-                sx = (uint32_t)min(max((int)floorf((ux - (float)cxx) * 8.0f), 0), 7);
-                sy = (uint32_t)min(max((int)floorf((uy - (float)cyy) * 8.0f), 0), 7);
+                const int sx = min(max((int)floorf((ux - (float)cxx) * (float)kSub), 0), kSub - 1);
+                const int sy = min(max((int)floorf((uy - (float)cyy) * (float)kSub), 0), kSub - 1);
+                rmask = (1u << (kIdxBits + sx)) | (1u << (kIdxBits + kSub + sy));
                 // depth level of the own-face hit, rounded up: anything quantised deeper cannot occlude
                 const float zs = t_self * gg.dir.z;
-                rq = (uint32_t)min(max((int)floorf((zs * 1.00002f - g.z0) * g.inv_qz) + 1, 0), g.zmax);
+                const uint32_t rq = (uint32_t)min(max((int)floorf((zs * 1.00002f - g.z0) * g.inv_qz) + 1, 0), g.zmax);
+                rlim = (rq << 25) | 0x1FFFFFFu;
                 const int c = cyy * R + cxx;
                 e1 = s_cell[c];
                 e = c > 0 ? s_cell[c - 1] : 0u;
@@ -873,16 +881,14 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
 #ifdef NLOS_FWD_STAMPS
             if (grid_ray) c_rays += 1;
 #endif
-            const uint32_t imask = (1u << g.ib) - 1u;
+            constexpr uint32_t imask = (1u << kIdxBits) - 1u;
             while (__any(e < e1)) {
                 bool pass = false;
                 int k = 0;
                 if (e < e1) {
                     const uint32_t w = s_ent[e++];
-                    const uint32_t fw = w >> g.ib;
                     k = (int)(w & imask);
-                    pass = (sx >= (fw & 7u)) & (sx <= ((fw >> 3) & 7u)) & (sy >= ((fw >> 6) & 7u)) &
-                           (sy <= ((fw >> 9) & 7u)) & ((fw >> 12) <= rq) & (k != j);
+                    pass = (w <= rlim) & ((w & rmask) == rmask) & (k != j);
                 }
 #ifdef NLOS_FWD_STAMPS
                 if (e <= e1 && grid_ray) c_pairs += 1;
@@ -1434,7 +1440,7 @@ constexpr size_t kGridLdsBudget = 78 * 1024;
 
 template <int FEAT>
 bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
-    if (a.force_bvh || a.sc.F > 65535 || a.sc.F < 64) return false;
+    if (a.force_bvh || a.sc.F > 8191 || a.sc.F < 64) return false;     // 13-bit triangle index in the cell entries
     int R = (int)lrintf(sqrtf(0.5f * (float)a.sc.F));
     R = std::min(std::max(R, 8), 96);
     const size_t nblk = ((size_t)a.sc.F + 63) / 64;
