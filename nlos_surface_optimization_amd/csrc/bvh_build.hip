@@ -6,7 +6,7 @@
 // moves every optimisation step, so the build must be cheap and stay on the
 // device: one 1024-thread workgroup runs all phases back to back
 //   bounds -> 30-bit Morton keys -> LDS-counted radix sort (6 x 5 bit) ->
-//   Karras radix tree + escape links -> bottom-up box refit + node emission
+//   Karras radix tree + escape links -> bottom-up box refit (in LDS while the inner nodes fit) + node emission
 // with workgroup barriers between phases (no host round trip, one launch,
 // graph-capturable).  Output is a stackless BVH: 32-byte nodes
 //   a = (lo.x, lo.y, lo.z, hi.x), b = (hi.y, hi.z, escape, link)
@@ -50,6 +50,15 @@ __device__ __forceinline__ int clamp_index(int v, int nV, int* status) {
     return v;
 }
 
+// order-preserving float <-> uint32 map (for LDS integer min/max atomics on box coordinates)
+__device__ __forceinline__ uint32_t fkey(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
 __device__ __forceinline__ void emit_node(const BuildArgs& a, int id, const float* b, int esc, int link) {
     a.nodes[2 * id] = make_float4(b[0], b[1], b[2], b[3]);
     a.nodes[2 * id + 1] = make_float4(b[4], b[5], __int_as_float(esc), __int_as_float(link));
@@ -57,7 +66,7 @@ __device__ __forceinline__ void emit_node(const BuildArgs& a, int id, const floa
 
 }  // namespace
 
-__global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a) {
+__global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words) {
     extern __shared__ uint32_t s_dyn[];       // radix counters [RDIG * BT] (128 KB)
     __shared__ uint32_t s_wsum[BT / 64];
     __shared__ float s_red[6 * 16];           // per-wave bounds
@@ -185,6 +194,20 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a) {
 
     // ---- phase 4: Karras radix tree ------------------------------------------------
     const int n_int = F - 1;
+    // Refit in LDS when the inner nodes fit (28 B each: parent word with an "arrived" flag in bit 31 +
+    // six order-preserving box keys).  The bottom-up walk is a chain of up to ~30 dependent levels
+    // towards the root; with global atomics + fences every level costs microseconds (0.2 ms in
+    // total, 70 % of the whole build), in LDS a few hundred cycles.
+    const bool lds_refit = n_int > 0 && 7 * n_int <= lds_words;
+    uint32_t* s_par = s_dyn;                     // [n_int]
+    uint32_t* s_box = s_dyn + n_int;             // [6 * n_int]: 0..2 min keys, 3..5 max keys
+    if (lds_refit) {
+        for (int i = tid; i < n_int; i += BT) {
+            for (int c = 0; c < 3; ++c) { s_box[6 * i + c] = 0xFFFFFFFFu; s_box[6 * i + 3 + c] = 0u; }
+            if (i == 0) s_par[0] = 0x7FFFFFFFu;  // root: no parent
+        }
+        __syncthreads();
+    }
     for (int i = tid; i < n_int; i += BT) {
         int d = (delta(keys, F, i, i + 1) - delta(keys, F, i, i - 1)) >= 0 ? 1 : -1;
         int dmin = delta(keys, F, i, i - d);
@@ -211,6 +234,10 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a) {
         a.parent[left] = i;
         a.parent[right] = i;
         a.arrive[i] = 0;
+        if (lds_refit) {
+            if (left < n_int) s_par[left] = (uint32_t)i;
+            if (right < n_int) s_par[right] = (uint32_t)i;
+        }
     }
     if (tid == 0) a.parent[F > 1 ? 0 : n_int] = -1;
     __syncthreads();
@@ -244,14 +271,35 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a) {
         a.facerec[4 * j + 3] = make_float4(__int_as_float(i2), 0.0f, 0.0f, 0.0f);
         a.face_id[j] = f;
         a.tri_zmin[j] = fminf(fminf(p0.z, p1.z), p2.z);
+        float lb6[6];
+        lb6[0] = fminf(fminf(p0.x, p1.x), p2.x) - pad;
+        lb6[1] = fminf(fminf(p0.y, p1.y), p2.y) - pad;
+        lb6[2] = fminf(fminf(p0.z, p1.z), p2.z) - pad;
+        lb6[3] = fmaxf(fmaxf(p0.x, p1.x), p2.x) + pad;
+        lb6[4] = fmaxf(fmaxf(p0.y, p1.y), p2.y) + pad;
+        lb6[5] = fmaxf(fmaxf(p0.z, p1.z), p2.z) + pad;
+        emit_node(a, n_int + j, lb6, escape_of(j), ~j);
+        if (lds_refit) {
+            // merge into the parent's box with LDS min/max atomics, then raise the parent's flag; the
+            // second arriver finds the box complete, takes it as its own and continues one level up
+            uint32_t key[6];
+            for (int c = 0; c < 6; ++c) key[c] = fkey(lb6[c]);
+            uint32_t node = F > 1 ? (uint32_t)a.parent[n_int + j] : 0x7FFFFFFFu;
+            while (node != 0x7FFFFFFFu) {
+                for (int c = 0; c < 3; ++c) atomicMin(&s_box[6 * node + c], key[c]);
+                for (int c = 3; c < 6; ++c) atomicMax(&s_box[6 * node + c], key[c]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                const uint32_t old = atomicOr(&s_par[node], 0x80000000u);
+                if (!(old & 0x80000000u)) break;          // sibling subtree not finished yet
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                for (int c = 0; c < 6; ++c)
+                    key[c] = __hip_atomic_load(&s_box[6 * node + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                node = old & 0x7FFFFFFFu;
+            }
+            continue;
+        }
         float* b = a.box + 6 * (size_t)(n_int + j);
-        b[0] = fminf(fminf(p0.x, p1.x), p2.x) - pad;
-        b[1] = fminf(fminf(p0.y, p1.y), p2.y) - pad;
-        b[2] = fminf(fminf(p0.z, p1.z), p2.z) - pad;
-        b[3] = fmaxf(fmaxf(p0.x, p1.x), p2.x) + pad;
-        b[4] = fmaxf(fmaxf(p0.y, p1.y), p2.y) + pad;
-        b[5] = fmaxf(fmaxf(p0.z, p1.z), p2.z) + pad;
-        emit_node(a, n_int + j, b, escape_of(j), ~j);
+        for (int c = 0; c < 6; ++c) b[c] = lb6[c];
         // One workgroup = one CU: a workgroup-scope release (s_waitcnt vmcnt(0): the write-through
         // stores have reached the L2) orders the box before the arrival count; the second arriver
         // reads the sibling's box with L1-bypassing loads.  No device-wide cache flushes needed.
@@ -276,14 +324,27 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a) {
             node = a.parent[node];
         }
     }
+    if (lds_refit) {
+        __syncthreads();
+        for (int i = tid; i < n_int; i += BT) {
+            float nb[6];
+            for (int c = 0; c < 6; ++c) nb[c] = fkey_inv(s_box[6 * i + c]);
+            emit_node(a, i, nb, escape_of(a.range[2 * i + 1]), a.child[2 * i]);
+        }
+    }
     NLOS_STAMP();
 }
 
 void launch_build_bvh(const BuildArgs& a, hipStream_t stream) {
-    const size_t lds = ((size_t)RDIG * BT + (size_t)RDIG * BT / 32 + 32) * sizeof(uint32_t);
+    // dynamic LDS: the radix counters (132 KB), or 28 B per inner node for the LDS refit if that is more
+    // and still fits beside the static arrays (160 KB per CU)
+    size_t lds = ((size_t)RDIG * BT + (size_t)RDIG * BT / 32 + 32) * sizeof(uint32_t);
+    const size_t refit = 7 * sizeof(uint32_t) * (size_t)(a.F > 1 ? a.F - 1 : 0);
+    const size_t lds_max = 160 * 1024 - 1024;
+    if (refit > lds && refit <= lds_max) lds = refit;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_bvh), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    hipLaunchKernelGGL(k_build_bvh, dim3(1), dim3(BT), lds, stream, a);
+    hipLaunchKernelGGL(k_build_bvh, dim3(1), dim3(BT), lds, stream, a, (int)(lds / sizeof(uint32_t)));
 }
 
 }  // namespace nlos
