@@ -1128,7 +1128,8 @@ __device__ __forceinline__ int tap_bin(double twoh, double delta, double lb, dou
 // values, so sum_i w_i d[bin_i] = sum_b d[b] * (P0[end_b] - P0[start_b]) with host-side prefix sums
 // P0 = cumsum(float(w)), P1 = cumsum(g * float(w)).  The boundary tap of every bin is located from
 // the closed form and then verified with the exact per-tap bin formula, so tap->bin assignment is
-// identical to the reference's literal loop.
+// identical to the reference's literal loop (the exact check runs only when the closed-form boundary
+// falls within 1e-4 of a tap, 100x the rounding of the tap offsets).
 struct TapTables {
     const double* delta;   // [K]
     const double* p0;      // [K+1]
@@ -1150,11 +1151,17 @@ __device__ __forceinline__ void grouped_taps(const TapTables& tt, const double* 
         int ie = K;
         if (b < b_last) {
             // first tap whose bin exceeds b: delta_i >= (b+1)*res + lb - 2h
-            double thr = ((double)(b + 1) * resd + lbd) - twoh;
-            int ic = (int)ceil(thr * tt.r_over_res) + tt.two_rs;
+            const double thr = ((double)(b + 1) * resd + lbd) - twoh;
+            const double y = thr * tt.r_over_res;          // boundary in (continuous) tap index, minus two_rs
+            const double yc = ceil(y);
+            int ic = (int)yc + tt.two_rs;
             ic = max(i_start, min(K, ic));
-            while (ic > i_start && tap_bin(twoh, tt.delta[ic - 1], lbd, resd, inv_res) > b) --ic;
-            while (ic < K && tap_bin(twoh, tt.delta[ic], lbd, resd, inv_res) <= b) ++ic;
+            // delta_i carries the fp32 rounding of (i - two_rs) * res / refine (<= ~1e-6 taps): the closed
+            // form is the reference's per-tap assignment unless the boundary is that close to a tap
+            if (yc - y < 1e-4 || y - (yc - 1.0) < 1e-4) {
+                while (ic > i_start && tap_bin(twoh, tt.delta[ic - 1], lbd, resd, inv_res) > b) --ic;
+                while (ic < K && tap_bin(twoh, tt.delta[ic], lbd, resd, inv_res) <= b) ++ic;
+            }
             ie = ic;
         }
         if (b >= 0 && b < T && ie > i_start) {
@@ -1169,8 +1176,12 @@ __device__ __forceinline__ void grouped_taps(const TapTables& tt, const double* 
 // MODE 0: per-vertex gradient [V,3]; 1: scalar d/d albedo; 2: scalar d/d alpha (GGX);
 //      3: single-vertex per-bin gradient [T,3]
 // two 512-thread workgroups per CU (LDS: ~76 KB each) need <= 128 VGPRs
+#ifndef NLOS_GRAD_NT
+#define NLOS_GRAD_NT 512
+#define NLOS_GRAD_WPS 4
+#endif
 template <int FEAT, int MODE, bool NC = false>
-__global__ __launch_bounds__(512, 4) void k_gradient(GradientArgs a) {
+__global__ __launch_bounds__(NLOS_GRAD_NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) {
     extern __shared__ double s_mem[];       // [ticket (8 B)][diff row T][tap tables 3K+2][grad 3V][masks][bases][live]
     int* s_next = reinterpret_cast<int*>(s_mem);
     const int T = a.sp.nbins;
@@ -1491,7 +1502,7 @@ template <int FEAT, int MODE>
 void gradient_launch2(const GradientArgs& a, int grid, size_t lds, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, MODE>), dim3(grid), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, MODE>), dim3(grid), dim3(NLOS_GRAD_NT), lds, stream, a);
 }
 
 template <int FEAT>
@@ -1500,7 +1511,7 @@ void gradient_launch(const GradientArgs& a, int grid, size_t lds, hipStream_t st
         if constexpr ((FEAT & FEAT_GGX) == 0) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, 0, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, 0, true>), dim3(grid), dim3(512), lds, stream, a);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, 0, true>), dim3(grid), dim3(NLOS_GRAD_NT), lds, stream, a);
         }
         return;
     }
