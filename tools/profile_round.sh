@@ -11,5 +11,6 @@ timeout 120 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU 
 timeout 120 rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_LDS_ATOMIC SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/sq2 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/sq2.log 2>&1
 python3 tools/pmc_summary.py $OUT > $OUT/pmc_summary_all.json
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+python3 tools/trace_summary.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) > $OUT/kernel_trace_summary.json
 tail -1 $OUT/trace.log > $OUT/bench_line_under_profiler.json
 cat $OUT/kernel_stats.csv | cut -c1-200
