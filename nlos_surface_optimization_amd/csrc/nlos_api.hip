@@ -81,6 +81,7 @@ struct nlos_ctx {
     // render scratch
     DevBuf vis, diff, fine, taps, rows_tmp, grad_tmp, live;
     DevBuf reg_normal, reg_area, reg_owner;
+    DevBuf vis2;
     int tap_refine = -1, tap_sigma = -1; float tap_res = -1.0f; int tap_kind = -1;
     // host-pointer path staging
     DevBuf io[16];
@@ -281,7 +282,7 @@ void nlos_ctx_destroy(nlos_ctx* c) {
     DeviceGuard g(c->device);
     DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                      &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live};
+                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2};
     for (DevBuf* b : all) b->release();
     for (DevBuf& b : c->io) b.release();
     for (hipEvent_t& e : c->ring) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
@@ -292,7 +293,7 @@ int64_t nlos_ctx_scratch_bytes(const nlos_ctx* c) {
     if (!c) return 0;
     const DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                            &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live};
+                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2};
     int64_t s = 0;
     for (const DevBuf* b : all) s += (int64_t)b->cap;
     for (const DevBuf& b : c->io) s += (int64_t)b.cap;
@@ -461,6 +462,13 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.dbg = c->status.as<long long>();     // 8 x int64 (diagnostic build only)
 #endif
     fa.rows = nullptr;
+    fa.vis2 = nullptr;
+    if (a->sensor && fa.live && nF <= 8191) {
+        // sensor-leg visibility bits of the two-pass grid path for non-confocal pairs
+        rc = c->vis2.ensure(sizeof(uint32_t) * (size_t)(L > 0 ? L : 1) * vis_words * nF + 16);
+        if (rc) return rc;
+        fa.vis2 = c->vis2.as<uint32_t>();
+    }
     nlos_ctx::VisKey key;
     key.L = L; key.F = nF; key.V = nV; key.spt = spt; key.off = a->source_offset; key.seed = a->seed;
     key.lb = lb; key.ub = ub;

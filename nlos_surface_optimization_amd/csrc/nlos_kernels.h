@@ -74,6 +74,7 @@ struct ForwardArgs {
     int force_bvh;           // 1: never use the per-source perspective grid (tests / large meshes)
     long long* dbg;          // diagnostic builds only (NLOS_FWD_STAMPS); null in the product
     uint16_t* live;          // [L, F] scratch: per-source bucketed list of contributing faces (grid kernel)
+    uint32_t* vis2;          // [L, vis_words, F] scratch: sensor-leg visibility of non-confocal pairs (grid path) or null
 };
 void launch_forward(const ForwardArgs& a, hipStream_t stream);
 

@@ -563,7 +563,11 @@ __device__ __forceinline__ void raster_tri(const GridView& g, const Proj2& q, Fn
 }
 
 // two 512-thread workgroups per CU = 4 waves per SIMD: keep the kernel within 128 VGPRs
-template <int FEAT>
+// NCM (row N, non-confocal pairs): 0 = confocal; 1 = visibility-only pass from the SENSOR of each pair
+// (bits -> a.vis2, no histogram); 2 = pass from the LASER that evaluates both legs' geometry, ANDs the
+// sensor-leg bits and traces only the laser leg.  One perspective grid serves one origin, so a pair costs
+// two grid passes (about 2x the confocal forward) instead of two BVH traversals per sample (9x).
+template <int FEAT, int NCM = 0>
 __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows_in_lds, int R, int cap) {
     // dynamic LDS: [ctl: ticket, bad, total, n_live (16 B)][row nbins f64][cells R*R+1 u32]
     //   [union { build: depth bound per 2x2 cells R2*R2 u32, block masks nblk u64 ;
@@ -590,8 +594,11 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     const int l = blockIdx.x;
     const int tid = threadIdx.x, NT = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = NT >> 6;
-    const V3 o = ld3(a.src.origin + 3 * (size_t)l);
-    const V3 on = ld3(a.src.normal + 3 * (size_t)l);
+    const V3 o = ld3((NCM == 1 ? a.src.sensor : a.src.origin) + 3 * (size_t)l);
+    const V3 on = ld3((NCM == 1 ? a.src.sensor_normal : a.src.normal) + 3 * (size_t)l);
+    const V3 ob = NCM == 2 ? ld3(a.src.sensor + 3 * (size_t)l) : o;
+    const V3 onb = NCM == 2 ? ld3(a.src.sensor_normal + 3 * (size_t)l) : on;
+    uint32_t* const visout = NCM == 1 ? a.vis2 : a.vis;
 #ifdef NLOS_FWD_STAMPS
     // diagnostic build only: per-phase cycles summed over workgroups -> a.dbg[0..5]
     long long t_prev = clock64();
@@ -652,8 +659,8 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
                 dark = behind && infront;
             }
             live = !dark;
-            if (dark && a.vis) {
-                uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
+            if (dark && visout) {
+                uint32_t* visp = visout + ((size_t)l * a.vis_words) * F + j;
                 for (int wi = 0; wi < a.vis_words; ++wi) visp[(size_t)wi * F] = 0u;
             }
             if (live && frame_ok) {
@@ -808,45 +815,80 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
         const bool has_face = li < n_live;
         const int j = has_face ? (int)g_live[li] : 0;
         const Face f = load_face(a.sc.facerec, j);
-        uint32_t* visp = (a.vis && has_face) ? a.vis + ((size_t)l * a.vis_words) * F + j : nullptr;
+        uint32_t* visp = (visout && has_face) ? visout + ((size_t)l * a.vis_words) * F + j : nullptr;
+        const uint32_t* visb = (NCM == 2 && has_face) ? a.vis2 + ((size_t)l * a.vis_words) * F + j : nullptr;
         const Tri tr = load_tri(a.sc.tris, j);
         const uint64_t kbase = (lg * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
-        uint32_t word = 0;
+        uint32_t word = 0, word_b = 0;
         double inten = 0.0;
         for (int s = 0; s < spt; ++s) {
             TMARK();
-            Geo gg;
-            float t_self = 0.0f;
+            V3 dir = mk(0.0f, 0.0f, 1.0f);
+            float t_self = 0.0f, val = 0.0f;
+            int bin = -1;
             bool ok = has_face;
-            if (ok)
-                ok = sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, lb, ub, a.sc.vertex_normal,
-                                      a.sc.albedo, gg, t_self);
-            float val = 0.0f;
-            if (ok) {
-                float ff = -dot(gg.n, gg.dir) * dot(on, gg.dir) / gg.h / gg.h;
-                if (a.sp.clamp) {
-                    ff = emax0(ff);
-                    ok = ff > 0.0f;
+            if (NCM == 2 && (s & 31) == 0 && has_face) word_b = visb[(size_t)(s >> 5) * F];
+            if (NCM == 0) {
+                Geo gg;
+                if (ok)
+                    ok = sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, lb, ub, a.sc.vertex_normal,
+                                          a.sc.albedo, gg, t_self);
+                if (ok) {
+                    float ff = -dot(gg.n, gg.dir) * dot(on, gg.dir) / gg.h / gg.h;
+                    if (a.sp.clamp) {
+                        ff = emax0(ff);
+                        ok = ff > 0.0f;
+                    }
+                    val = f.area * gg.alb * ff * ff;
+                    if (FEAT & FEAT_GGX) val = val * ggx_eval(a.sp.ggx_alpha, dot(gg.n, -gg.dir));
+                    bin = (int)floorf((2.0f * gg.h - lb) / res);
+                    dir = gg.dir;
                 }
-                val = f.area * gg.alb * ff * ff;
-                if (FEAT & FEAT_GGX) val = val * ggx_eval(a.sp.ggx_alpha, dot(gg.n, -gg.dir));
+            } else if (NCM == 1) {
+                // sensor leg only: is the stratified point the closest hit seen from the sensor?
+                if (ok) {
+                    float S, T;
+                    sample_st(a.sp.seed, kbase + (uint64_t)s, S, T);
+                    const float sq = sqrtf(T);
+                    const V3 p = bary(1 - sq, f.p0, (1 - S) * sq, f.p1, S * sq, f.p2);
+                    const V3 d = p - o;
+                    dir = d * (1.0f / sqrtf(dot(d, d)));
+                    float hu, hv;
+                    ok = tri_test(tr, o, dir, t_self, hu, hv);
+                    // a leg whose form factor is exactly zero is rejected by the laser pass anyway: skip its ray
+                    if (ok && !(FEAT & FEAT_VN)) ok = (-dot(f.fn, dir) * dot(on, dir)) > 0.0f;
+                }
+            } else {
+                GeoNC gc;
+                float t_b;
+                if (ok)
+                    ok = sample_geo_nc<FEAT>(f, tr, o, ob, a.sp.seed, kbase + (uint64_t)s, lb, ub, a.sc.vertex_normal,
+                                             a.sc.albedo, gc, t_self, t_b);
+                if (ok) {
+                    const float ffa = emax0(-dot(gc.n, gc.dirA) * dot(on, gc.dirA) / gc.d1 / gc.d1);
+                    const float ffb = emax0(-dot(gc.n, gc.dirB) * dot(onb, gc.dirB) / gc.d2 / gc.d2);
+                    ok = ffa > 0.0f && ffb > 0.0f && ((word_b >> (s & 31)) & 1u);
+                    val = f.area * gc.alb * ffa * ffb;
+                    bin = (int)floorf(((gc.d1 + gc.d2) - lb) / res);
+                    dir = gc.dirA;
+                }
             }
-            if (!ok) { gg.dir = mk(0.0f, 0.0f, 1.0f); gg.h = 1.0f; }
-            const bool grid_ray = ok && use_grid && gg.dir.z > 0.0f;
+            if (!ok) dir = mk(0.0f, 0.0f, 1.0f);
+            const bool grid_ray = ok && use_grid && dir.z > 0.0f;
             if (ok && !grid_ray)
-                ok = !occluded(a.sc.nodes, a.sc.n_nodes, a.sc.tris, a.sc.face_id, o, gg.dir, t_self, j, f.fid);
+                ok = !occluded(a.sc.nodes, a.sc.n_nodes, a.sc.tris, a.sc.face_id, o, dir, t_self, j, f.fid);
 
             // ---- stage 1 + 2 (wave-synchronous; every lane takes part) ----
             uint32_t e = 0, e1 = 0, rmask = 0, rlim = 0;
             if (grid_ray) {
-                const float iz = __builtin_amdgcn_rcpf(gg.dir.z);   // lookups only: 1-ulp rcp is fine
-                const float ux = (gg.dir.x * iz - g.gx0) * g.inv_cw, uy = (gg.dir.y * iz - g.gy0) * g.inv_ch;
+                const float iz = __builtin_amdgcn_rcpf(dir.z);   // lookups only: 1-ulp rcp is fine
+                const float ux = (dir.x * iz - g.gx0) * g.inv_cw, uy = (dir.y * iz - g.gy0) * g.inv_ch;
                 const int cxx = min(max((int)floorf(ux), 0), R - 1), cyy = min(max((int)floorf(uy), 0), R - 1);
                 const int sx = min(max((int)floorf((ux - (float)cxx) * (float)kSub), 0), kSub - 1);
                 const int sy = min(max((int)floorf((uy - (float)cyy) * (float)kSub), 0), kSub - 1);
                 rmask = (1u << (kIdxBits + sx)) | (1u << (kIdxBits + kSub + sy));
                 // depth level of the own-face hit, rounded up: anything quantised deeper cannot occlude
-                const float zs = t_self * gg.dir.z;
+                const float zs = t_self * dir.z;
                 const uint32_t rq = (uint32_t)min(max((int)floorf((zs * 1.00002f - g.z0) * g.inv_qz) + 1, 0), g.zmax);
                 rlim = (rq << 25) | 0x1FFFFFFu;
                 const int c = cyy * R + cxx;
@@ -864,7 +906,7 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
                 __builtin_amdgcn_wave_barrier();
                 const uint32_t pr = wq[lane < n ? lane : 0];
                 const int owner = (int)(pr >> 16), k = (int)(pr & 0xFFFFu);
-                const V3 od = mk(__shfl(gg.dir.x, owner), __shfl(gg.dir.y, owner), __shfl(gg.dir.z, owner));
+                const V3 od = mk(__shfl(dir.x, owner), __shfl(dir.y, owner), __shfl(dir.z, owner));
                 const float ot = __shfl(t_self, owner);
                 const int ofid = __shfl(f.fid, owner);
                 if (lane < n) {
@@ -930,15 +972,14 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
 
             if (ok) {
                 word |= 1u << (s & 31);
-                if (a.mode_intensity) {
+                if (NCM == 1) {
+                    // visibility only
+                } else if (a.mode_intensity) {
                     inten += (double)val / (double)spt;
-                } else {
-                    int bin = (int)floorf((2.0f * gg.h - lb) / res);
-                    if (bin >= 0 && bin < nbins) {
-                        double cc = (double)val / (double)spt;
-                        if (rows_in_lds) unsafeAtomicAdd(&s_row[bin], cc);
-                        else unsafeAtomicAdd(&grow[bin], cc);
-                    }
+                } else if (bin >= 0 && bin < nbins) {
+                    double cc = (double)val / (double)spt;
+                    if (rows_in_lds) unsafeAtomicAdd(&s_row[bin], cc);
+                    else unsafeAtomicAdd(&grow[bin], cc);
                 }
             }
             if ((s & 31) == 31 || s == spt - 1) {
@@ -1460,7 +1501,7 @@ __global__ __launch_bounds__(256) void k_zero_f64(double* p, size_t n) {
 // LDS budget of the grid kernel: two 512-thread workgroups per CU (160 KiB / 2, minus slack)
 constexpr size_t kGridLdsBudget = 78 * 1024;
 
-template <int FEAT>
+template <int FEAT, int NCM = 0>
 bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
     if (a.force_bvh || a.sc.F > 8191 || a.sc.F < 64) return false;     // 13-bit triangle index in the cell entries
     int R = (int)lrintf(sqrtf(0.5f * (float)a.sc.F));
@@ -1474,10 +1515,10 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
     if (fixed + 4 * 2 * (size_t)a.sc.F > kGridLdsBudget || !a.live) return false;      // want room for >= 2 entries per face
     size_t cap = (kGridLdsBudget - fixed) / 4;
     const size_t lds = fixed + cap * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // one slot of slack: the walk reads entries in pairs and may touch the slot after the last list
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT>), dim3(a.src.L), dim3(512), lds, stream, a, rows_in_lds, R,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM>), dim3(a.src.L), dim3(512), lds, stream, a, rows_in_lds, R,
                        (int)cap - 1);
     return true;
 }
@@ -1485,9 +1526,17 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
 template <int FEAT>
 void forward_launch(const ForwardArgs& a, int rows_in_lds, size_t lds, hipStream_t stream) {
     if (a.src.sensor) {
-        // row N: two shadow legs per sample through the BVH (the per-source grid serves one origin)
-        if constexpr ((FEAT & FEAT_GGX) == 0)
+        if constexpr ((FEAT & FEAT_GGX) == 0) {
+            // row N: one grid pass per end point of the pair (sensor-leg visibility bits first, then the
+            // laser pass that ANDs them and bins); ...
+            if (a.vis2 && !a.mode_intensity) {
+                ForwardArgs p1 = a;
+                p1.rows = nullptr;
+                if (forward_grid_launch<FEAT, 1>(p1, 0, stream) && forward_grid_launch<FEAT, 2>(a, rows_in_lds, stream)) return;
+            }
+            // ... or, for meshes the grid cannot hold, two shadow legs per sample through the BVH
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_nc<FEAT, 4>), dim3(a.src.L), dim3(256), lds, stream, a, rows_in_lds);
+        }
         return;
     }
     if (forward_grid_launch<FEAT>(a, rows_in_lds, stream)) return;

@@ -496,3 +496,32 @@ def test_mesh_regularisers_vs_oracle(bunny, orc):
     assert np.abs(tg.cpu().numpy() - g0).max() <= 1e-12 * np.abs(g0).max()
     none, tg2 = r.mesh_regulariser(tv, tf_)
     assert none is None and np.abs(tg2.cpu().numpy() - ga0).max() <= 1e-12 * np.abs(ga0).max()
+
+
+def test_nonconfocal_grid_and_bvh_paths_agree(bunny):
+    """Row N has two back-ends (two perspective-grid passes, one per end point of the pair; or two BVH
+    shadow legs per sample): identical accept/reject decisions, so identical rows up to fp64 order."""
+    import torch
+    from nlos_surface_optimization_amd import device as nd
+    v, f = bunny
+    a, na, b, nb = _nc_pairs(6)
+    dev = torch.device("cuda", 0)
+    r = nd.TransientRenderer(dev, seed=2)
+    tv, tf_ = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
+    ta, tna, tb, tnb = (torch.from_numpy(x).to(dev) for x in (a, na, b, nb))
+    tg, _ = r.render_transient(ta, tna, tv, tf_, 20000, LB, UB, RES, sensor=tb, sensor_normal=tnb)
+    tbv, _ = r.render_transient(ta, tna, tv, tf_, 20000, LB, UB, RES, sensor=tb, sensor_normal=tnb, force_bvh=True)
+    assert tg.sum().item() > 0
+    assert (tg - tbv).abs().max().item() <= 1e-13 * tg.max().item()
+    data = tg * 1.2
+    w = torch.ones_like(tg)
+    _, gg, _ = r.render_gradient(ta, tna, tv, tf_, 20000, LB, UB, RES, data=data, weight=w, sensor=tb, sensor_normal=tnb)
+    _, gb, _ = r.render_gradient(ta, tna, tv, tf_, 20000, LB, UB, RES, data=data, weight=w, sensor=tb, sensor_normal=tnb,
+                                 force_bvh=True)
+    assert rel_l2(gg.cpu().numpy(), gb.cpu().numpy()) <= 1e-6
+    # a pair whose sensor sits behind the scene's front plane exercises the in-kernel BVH fallback of pass 1
+    tb2 = tb.clone()
+    tb2[0, 2] = 0.45
+    t1, _ = r.render_transient(ta, tna, tv, tf_, 20000, LB, UB, RES, sensor=tb2, sensor_normal=tnb)
+    t2, _ = r.render_transient(ta, tna, tv, tf_, 20000, LB, UB, RES, sensor=tb2, sensor_normal=tnb, force_bvh=True)
+    assert (t1 - t2).abs().max().item() <= 1e-13 * max(t1.max().item(), 1e-30)
