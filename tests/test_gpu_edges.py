@@ -1,0 +1,123 @@
+"""Edge cases of the hot path on the GPU (SURVEY.md section 9 quirks and the reference's argument
+checks): empty / tiny / degenerate / ragged inputs, rows that do not fit LDS, out-of-range indices,
+samples on the range limits, deterministic re-runs."""
+import numpy as np
+import pytest
+
+from conftest import grid_sources, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+LB, UB, RES, T = 0.625, 1.625, 2.0 ** -9, 512
+
+
+def _render(v, f, o, n, ns, lb=LB, ub=UB, res=RES, refine=10, sb=1, data=None, weight=None):
+    from nlos_surface_optimization_amd import renderer
+    nb = renderer._num_bins(lb, ub, res)
+    tr, path, grad = np.zeros((o.shape[0], nb)), np.zeros(nb), np.zeros((v.shape[0], 3))
+    if data is None:
+        renderer.renderStreamedTransient(o, n, v, f, ns, lb, ub, res, tr, path, 1, 1)
+        return tr, None, path
+    renderer.renderStreamedGradient(o, n, v, f, ns, lb, ub, res, tr, path, grad, data, weight, refine, sb, 1, 0)
+    return tr, grad, path
+
+
+def test_empty_sources_and_single_face(orc):
+    v = np.array([[-.1, -.1, .5], [.1, -.1, .5], [0, .1, .52]], np.float32)
+    f = np.array([[0, 2, 1]], np.int32)
+    o0 = np.zeros((0, 3), np.float32)
+    tr, _, path = _render(v, f, o0, o0.copy(), 64)
+    assert tr.shape == (0, T) and np.array_equal(path, (np.float32(LB) + np.arange(T, dtype=np.float32) * np.float32(RES)).astype(np.float64))
+    tr, grad, _ = _render(v, f, o0, o0.copy(), 64, data=np.zeros((0, T)), weight=np.zeros((0, T)))
+    assert tr.shape == (0, T) and not grad.any()
+    # one face, spt = 64 (> 32: two visibility words per face), F < 64 -> the small-mesh BVH kernel
+    o, n = grid_sources(2, 0.1)
+    t_ref, _ = orc.render_transient(o, n, v, f, 64, LB, UB, RES)
+    tr, _, _ = _render(v, f, o, n, 64)
+    assert t_ref.sum() > 0 and rel_l2(tr, t_ref) <= 1e-12
+    d, w = t_ref * 0.5, np.ones_like(t_ref)
+    _, g_ref, _ = orc.render_gradient(o, n, v, f, 64, LB, UB, RES, d, w)
+    _, grad, _ = _render(v, f, o, n, 64, data=d, weight=w)
+    assert rel_l2(grad, g_ref) <= 1e-4
+
+
+def test_degenerate_and_duplicate_faces_contribute_like_the_oracle(bunny, orc):
+    v, f = bunny
+    f2 = f.copy()
+    f2[10] = [f[10, 0], f[10, 0], f[10, 1]]          # zero-area face (the reference divides by zero here)
+    f2[11] = f2[12]                                   # exact duplicate: tie on t, the lower face id wins
+    o, n = grid_sources(2, 0.2)
+    t_ref, _ = orc.render_transient(o, n, v, f2, 20000, LB, UB, RES, accel=1)
+    tr, _, _ = _render(v, f2, o, n, 20000)
+    assert np.isfinite(tr).all() and rel_l2(tr, t_ref) <= 1e-12
+    d, w = t_ref * 1.3, np.ones_like(t_ref)
+    _, g_ref, _ = orc.render_gradient(o, n, v, f2, 20000, LB, UB, RES, d, w, accel=1)
+    _, grad, _ = _render(v, f2, o, n, 20000, data=d, weight=w)
+    assert np.isfinite(grad).all() and rel_l2(grad, g_ref) <= 1e-4
+
+
+def test_out_of_range_face_index_is_an_error_not_a_crash(bunny):
+    from nlos_surface_optimization_amd import _lib
+    v, f = bunny
+    bad = f.copy()
+    bad[5, 1] = v.shape[0] + 3
+    o, n = grid_sources(2, 0.2)
+    with pytest.raises(_lib.NlosError):
+        _render(v, bad, o, n, 20000)
+    bad[5, 1] = -1
+    with pytest.raises(_lib.NlosError):
+        _render(v, bad, o, n, 20000)
+    tr, _, _ = _render(v, f, o, n, 20000)             # the context is still usable afterwards
+    assert tr.sum() > 0
+
+
+def test_rows_that_do_not_fit_lds_and_refined_forward(bunny, orc):
+    """T = 16384 bins (128 KB per row: global-atomic histogram path) and the sigma_bin >= 5 refined
+    forward whose fine rows are T * refine = 5120 bins."""
+    v, f = bunny
+    o, n = grid_sources(2, 0.2)
+    res = 2.0 ** -14
+    t_ref, _ = orc.render_transient(o, n, v, f, 20000, LB, UB, res, accel=1)
+    tr, _, _ = _render(v, f, o, n, 20000, res=res)
+    assert tr.shape[1] == 16384 and rel_l2(tr, t_ref) <= 1e-12
+    d = np.zeros((4, T))
+    w = np.ones((4, T))
+    t5, g5, _ = orc.render_gradient(o, n, v, f, 20000, LB, UB, RES, d, w, refine=10, sigma_bin=5, accel=1)
+    tr, grad, _ = _render(v, f, o, n, 20000, refine=10, sb=5, data=d, weight=w)
+    assert rel_l2(tr, t5) <= 1e-5 and rel_l2(grad, g5) <= 1e-4
+
+
+def test_window_limits_and_out_of_window_mesh(bunny, orc):
+    """Samples beyond [lb/2, ub/2] are dropped, a window that misses the object renders zeros, and a
+    hit exactly on ub/2 (bin == T, one past the row in the reference) is skipped."""
+    v, f = bunny
+    o, n = grid_sources(2, 0.2)
+    tr, _, _ = _render(v, f, o, n, 20000, lb=0.0, ub=0.5, res=2.0 ** -9)
+    assert not tr.any()
+    t_ref, _ = orc.render_transient(o, n, v, f, 20000, 0.9, 1.1, 2.0 ** -9, accel=1)
+    tr, _, _ = _render(v, f, o, n, 20000, lb=0.9, ub=1.1, res=2.0 ** -9)
+    assert 0 < tr.sum() and rel_l2(tr, t_ref) <= 1e-12
+    # plane at distance exactly ub/2 straight above the source
+    pv = np.array([[-1, -1, .5], [1, -1, .5], [1, 1, .5], [-1, 1, .5]], np.float32)
+    pf = np.array([[0, 2, 1], [0, 3, 2]], np.int32)
+    o1 = np.zeros((1, 3), np.float32)
+    n1 = np.array([[0, 0, 1]], np.float32)
+    t_ref, _ = orc.render_transient(o1, n1, pv, pf, 4096, 0.0, 1.0, 2.0 ** -6)
+    tr, _, _ = _render(pv, pf, o1, n1, 4096, lb=0.0, ub=1.0, res=2.0 ** -6)
+    assert rel_l2(tr, t_ref) <= 1e-12 and np.isfinite(tr).all()
+
+
+def test_rerun_is_deterministic_up_to_summation_order_and_seed_matters(bunny):
+    from nlos_surface_optimization_amd import _lib
+    v, f = bunny
+    o, n = grid_sources(3, 0.2)
+    a, _, _ = _render(v, f, o, n, 20000)
+    b, _, _ = _render(v, f, o, n, 20000)
+    assert np.abs(a - b).max() <= 1e-15 * a.max()
+    _lib.lib().nlos_set_default_seed(12345)
+    try:
+        c, _, _ = _render(v, f, o, n, 20000)
+    finally:
+        _lib.lib().nlos_set_default_seed(0)
+    assert np.abs(a - c).max() > 1e-6 * a.max()                       # another stream of samples
+    assert abs(a.sum() - c.sum()) < 0.05 * a.sum()                    # same estimator
