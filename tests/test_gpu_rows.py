@@ -525,3 +525,67 @@ def test_nonconfocal_grid_and_bvh_paths_agree(bunny):
     t1, _ = r.render_transient(ta, tna, tv, tf_, 20000, LB, UB, RES, sensor=tb2, sensor_normal=tnb)
     t2, _ = r.render_transient(ta, tna, tv, tf_, 20000, LB, UB, RES, sensor=tb2, sensor_normal=tnb, force_bvh=True)
     assert (t1 - t2).abs().max().item() <= 1e-13 * max(t1.max().item(), 1e-30)
+
+
+# ------------------------------------------------------------------ BASELINE configs 4 and 5 (shapes, small L)
+def test_config4_shape_mannequin_nonconfocal_sharded(mannequin, orc):
+    """BASELINE config 4 at parity-test size: exp_mannequin mesh, non-confocal pairs, 1024 bins
+    (lb = 0, res = 2.4e-3, the reference's pairwise-summed mannequin data), sensor-block
+    sharding: two blocks (as two ranks render them, RNG keyed on the global pair index) == one render."""
+    import torch
+    from nlos_surface_optimization_amd import device as nd
+    from nlos_surface_optimization_amd.dist import shard_bounds
+    v, f = mannequin
+    lb, res = 0.0, 2.4e-3
+    ub = float(np.float32(1024) * np.float32(res))
+    ns = 4000
+    a, na = grid_sources(4, 0.35)
+    b = a[::-1].copy()                               # every laser looks at a different sensor point
+    nb = na.copy()
+    t_ref, _, _ = orc.render_nonconfocal(a, na, b, nb, v, f, ns, lb, ub, res, refine=1, accel=1)
+    assert t_ref.shape == (16, 1024) and t_ref.sum() > 0
+    rs = np.random.RandomState(3)
+    data = t_ref * (1 + 0.2 * rs.standard_normal(t_ref.shape))
+    w = np.ones_like(data)
+    t2, g_ref, _ = orc.render_nonconfocal(a, na, b, nb, v, f, ns, lb, ub, res, data=data, weight=w, accel=1)
+    assert np.array_equal(t2, t_ref)         # sigma_bin < 5: the gradient call's forward rows are the plain histogram
+    dev = torch.device("cuda", 0)
+    r = nd.TransientRenderer(dev)
+    tv, tf_ = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
+    ta, tna, tb, tnb = (torch.from_numpy(x).to(dev) for x in (a, na, b, nb))
+    td, tw = torch.from_numpy(data).to(dev), torch.from_numpy(w).to(dev)
+    tr, grad, _ = r.render_gradient(ta, tna, tv, tf_, ns, lb, ub, res, data=td, weight=tw, sensor=tb, sensor_normal=tnb)
+    assert rel_l2(tr.cpu().numpy(), t_ref) <= 1e-5 and rel_l2(grad.cpu().numpy(), g_ref) <= 1e-4
+    gsum = torch.zeros_like(grad)
+    rows = []
+    for rank in range(2):
+        lo, hi = shard_bounds(16, rank, 2)
+        t, g, _ = r.render_gradient(ta[lo:hi].contiguous(), tna[lo:hi].contiguous(), tv, tf_, ns, lb, ub, res,
+                                    data=td[lo:hi].contiguous(), weight=tw[lo:hi].contiguous(),
+                                    sensor=tb[lo:hi].contiguous(), sensor_normal=tnb[lo:hi].contiguous(),
+                                    source_offset=lo, total_sources=16)
+        rows.append(t)
+        gsum += g
+    assert torch.equal(torch.cat(rows), tr)
+    assert rel_l2(gsum.cpu().numpy(), grad.cpu().numpy()) <= 1e-12
+
+
+def test_config5_shape_ggx_poisson_noised_1024_bins(bunny, orc):
+    """BASELINE config 5 at parity-test size: GGX branch (alpha = 0.3), 1024 bins, measurement =
+    Poisson-noised clean transient + background (exp_noise/noise/addNoiseExample.m:9, numpy default_rng(0))."""
+    from nlos_surface_optimization_amd import ggx
+    v, f = bunny
+    o, n = grid_sources(2, 0.2)
+    lb, ub, res, ns = 0.625, 1.625, 2.0 ** -10, 20000
+    clean, _ = orc.render_transient(o, n, v, f, ns, lb, ub, res, ggx_alpha=0.3, accel=1)
+    rng = np.random.default_rng(0)
+    c = 2e4 / clean.sum(axis=1, keepdims=True)
+    data = rng.poisson(c * clean) / c + rng.poisson(0.05, clean.shape) / c
+    w = np.ones_like(data)
+    t_ref, g_ref, _ = orc.render_gradient(o, n, v, f, ns, lb, ub, res, data, w, ggx_alpha=0.3, testing_flag=1, accel=1)
+    a_ref = orc.render_gradient_scalar(o, n, v, f, ns, lb, ub, res, data, w, wrt_alpha=True, ggx_alpha=0.3, accel=1)[1]
+    tr, path, grad = np.zeros((4, 1024)), np.zeros(1024), np.zeros((v.shape[0], 3))
+    ggx.renderStreamedGradient(o, n, v, f, 0.3, ns, lb, ub, res, tr, path, grad, data, w, 10, 1, 1)
+    assert rel_l2(tr, t_ref) <= 1e-5 and rel_l2(grad, g_ref) <= 1e-4
+    ga = ggx.renderStreamedGradientAlpha(o, n, v, f, 0.3, ns, lb, ub, res, tr, path, data, w, 10, 1)
+    assert abs(ga - a_ref) <= 1e-4 * abs(a_ref)
