@@ -110,3 +110,39 @@ def face_affinity(f):
     out[fs[idx], ss[idx]] = fs[idx + 1]
     out[fs[idx + 1], ss[idx + 1]] = fs[idx]
     return np.ascontiguousarray(out)
+
+
+def read_transient_mat(path, fold=1):
+    """Measured data of the reference's real-data experiments as the hot path consumes it.
+
+    The shipped files (exp_mannequin/transient.mat, exp_s/transient.mat, exp_su/...) are MAT v5 with
+    `transient` uint8 [L, T] + `lighting` float64 [L, 3] (mannequin) or `rect_data` [R, R, T]
+    (exp_s/test.py:64-68); the scripts read them with scipy.io.loadmat and reshape ad hoc.
+    Returns a dict: `transient` float64 [L, T // fold] (C order; `fold` adjacent bins summed -- BASELINE
+    config 4 uses the 2048-bin mannequin data pairwise-summed to 1024), `lighting` float32 [L, 3] and
+    `lighting_normal` float32 [L, 3] = (0, 0, 1) when the file has `lighting`.
+    """
+    import scipy.io
+    m = scipy.io.loadmat(path)
+    if "transient" in m:
+        t = np.asarray(m["transient"], dtype=np.float64)
+    elif "rect_data" in m:
+        r = np.asarray(m["rect_data"], dtype=np.float64)
+        t = r.reshape(-1, r.shape[-1])
+    else:
+        raise ValueError("%s: no 'transient' or 'rect_data' array" % path)
+    if t.ndim != 2:
+        raise ValueError("%s: transient must be [L, T]" % path)
+    fold = int(fold)
+    if fold > 1:
+        if t.shape[1] % fold:
+            raise ValueError("number of bins %d is not a multiple of fold=%d" % (t.shape[1], fold))
+        t = t.reshape(t.shape[0], t.shape[1] // fold, fold).sum(axis=2)
+    out = {"transient": np.ascontiguousarray(t)}
+    if "lighting" in m:
+        lighting = np.ascontiguousarray(m["lighting"], dtype=np.float32)
+        if lighting.shape != (t.shape[0], 3):
+            raise ValueError("%s: lighting must be [L, 3]" % path)
+        out["lighting"] = lighting
+        out["lighting_normal"] = np.ascontiguousarray(np.tile(np.array([0, 0, 1], np.float32), (t.shape[0], 1)))
+    return out

@@ -27,3 +27,28 @@ def test_fixture_meshes_are_wall_facing_closed_enough(bunny, mannequin):
     for v, f in (bunny, mannequin):
         assert f.min() >= 0 and f.max() < v.shape[0]
         assert v[:, 2].min() > 0.2          # in front of the wall z = 0
+
+
+def test_read_transient_mat_layouts(tmp_path):
+    """The two layouts of the reference's shipped measurement files (MAT v5 written here with scipy)."""
+    import scipy.io
+    from nlos_surface_optimization_amd import mesh_io
+    rs = np.random.RandomState(0)
+    tr = rs.randint(0, 255, (16, 64)).astype(np.uint8)
+    li = rs.uniform(-0.35, 0.35, (16, 3))
+    li[:, 2] = 0
+    p = str(tmp_path / "transient.mat")
+    scipy.io.savemat(p, {"transient": tr, "lighting": li})
+    d = mesh_io.read_transient_mat(p, fold=2)
+    assert d["transient"].shape == (16, 32) and d["transient"].dtype == np.float64 and d["transient"].flags.c_contiguous
+    assert np.array_equal(d["transient"], tr[:, 0::2].astype(np.float64) + tr[:, 1::2])
+    assert d["lighting"].dtype == np.float32 and np.allclose(d["lighting"], li, atol=1e-7)
+    assert np.array_equal(d["lighting_normal"][3], [0, 0, 1])
+    rect = rs.random_sample((4, 4, 20))
+    q = str(tmp_path / "rect.mat")
+    scipy.io.savemat(q, {"rect_data": rect})
+    e = mesh_io.read_transient_mat(q)
+    assert e["transient"].shape == (16, 20) and np.array_equal(e["transient"][5], rect[1, 1]) and "lighting" not in e
+    import pytest
+    with pytest.raises(ValueError):
+        mesh_io.read_transient_mat(p, fold=5)
