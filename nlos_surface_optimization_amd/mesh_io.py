@@ -146,3 +146,25 @@ def read_transient_mat(path, fold=1):
         out["lighting"] = lighting
         out["lighting_normal"] = np.ascontiguousarray(np.tile(np.array([0, 0, 1], np.float32), (t.shape[0], 1)))
     return out
+
+
+def subdivide(v, f, times=1):
+    """1 -> 4 midpoint subdivision with shared edge midpoints (keeps the surface, multiplies F by 4 per
+    pass).  Used to build large synthetic meshes of a known shape for tests and side benchmarks."""
+    v = np.asarray(v, np.float32)
+    f = np.asarray(f, np.int64)
+    for _ in range(int(times)):
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], axis=0)
+        es = np.sort(e, axis=1)
+        key = es[:, 0] * (v.shape[0] + 1) + es[:, 1]
+        uk, inv = np.unique(key, return_inverse=True)
+        a = (uk // (v.shape[0] + 1)).astype(np.int64)
+        b = (uk % (v.shape[0] + 1)).astype(np.int64)
+        mid = ((v[a].astype(np.float64) + v[b]) / 2).astype(np.float32)
+        base = v.shape[0]
+        F = f.shape[0]
+        m01, m12, m20 = base + inv[:F], base + inv[F:2 * F], base + inv[2 * F:]
+        f = np.concatenate([np.stack([f[:, 0], m01, m20], 1), np.stack([m01, f[:, 1], m12], 1),
+                            np.stack([m20, m12, f[:, 2]], 1), np.stack([m01, m12, m20], 1)], axis=0)
+        v = np.concatenate([v, mid], axis=0)
+    return np.ascontiguousarray(v, np.float32), np.ascontiguousarray(f, np.int32)
