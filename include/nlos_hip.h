@@ -244,7 +244,9 @@ typedef struct nlos_render_args {
     int32_t reuse_visibility;   /* GRADIENT with residual: skip pass 1, reuse the cache recorded by the
                                    previous render on this ctx (same mesh, sources, samples, seed) */
     int32_t force_bvh;          /* 1: occlusion by BVH traversal only (default 0: per-source perspective
-                                   grid in LDS when the mesh fits, BVH otherwise; identical results) */
+                                   grid in LDS, tiled over several workgroups per source for meshes beyond
+                                   ~7.4 k faces; identical results).  2 (diagnostic): tiled grid with a tiny
+                                   per-tile capacity, to exercise the tiles' overflow fallback */
     /* non-confocal pairs (the reference has only Python prototypes of it:
      * transient_rendering_python/rendering.py:8-93, mesh_optimization/rendering.py:739-797).
      * NULL = confocal.  Otherwise measurement l is the pair (laser origin[l], sensor[l]): the

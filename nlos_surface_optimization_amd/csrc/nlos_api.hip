@@ -81,7 +81,7 @@ struct nlos_ctx {
     // render scratch
     DevBuf vis, diff, fine, taps, rows_tmp, grad_tmp, live;
     DevBuf reg_normal, reg_area, reg_owner;
-    DevBuf vis2;
+    DevBuf vis2, tile_list, tile_count;
     int tap_refine = -1, tap_sigma = -1; float tap_res = -1.0f; int tap_kind = -1;
     // host-pointer path staging
     DevBuf io[16];
@@ -282,7 +282,7 @@ void nlos_ctx_destroy(nlos_ctx* c) {
     DeviceGuard g(c->device);
     DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                      &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2};
+                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count};
     for (DevBuf* b : all) b->release();
     for (DevBuf& b : c->io) b.release();
     for (hipEvent_t& e : c->ring) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
@@ -293,7 +293,7 @@ int64_t nlos_ctx_scratch_bytes(const nlos_ctx* c) {
     if (!c) return 0;
     const DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                            &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2};
+                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count};
     int64_t s = 0;
     for (const DevBuf* b : all) s += (int64_t)b->cap;
     for (const DevBuf& b : c->io) s += (int64_t)b.cap;
@@ -449,13 +449,40 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.sp.nbins = rb;
     fa.vis = nullptr; fa.vis_words = vis_words;
     fa.intensity = a->intensity; fa.mode_intensity = mode == NLOS_MODE_INTENSITY ? 1 : 0;
-    fa.force_bvh = a->force_bvh;
+    fa.force_bvh = a->force_bvh == 1 ? 1 : 0;
     fa.dbg = nullptr;
     fa.live = nullptr;
-    if (nF <= 65535 && !a->force_bvh) {
+    fa.tile_list = nullptr;
+    fa.tile_count = nullptr;
+    fa.tiles_x = fa.tiles_y = fa.tile_cap = 0;
+    if (nF <= 7400 && a->force_bvh != 1) {
         rc = c->live.ensure(sizeof(uint16_t) * (size_t)(L > 0 ? L : 1) * nF + 16);
         if (rc) return rc;
         fa.live = c->live.as<uint16_t>();
+    } else if (a->force_bvh != 1 && !a->sensor && mode != NLOS_MODE_INTENSITY && L > 0) {
+        // tiled grid: ~3000 triangles per slope-space tile on average (small tiles leave the 512 threads idle); the densest tiles of a closed surface
+        // (front + back side, several depth layers) hold up to ~4.5x the mean, and the subset capacity is bounded by
+        // the 14-bit entry index (overflowing tiles fall back to the BVH query by themselves);
+        // scratch = 6 B per (source, tile, slot)
+        const int nt = (nF + 2999) / 3000;
+        int side = 1;
+        while (side * side < nt) ++side;
+        const long long tiles = (long long)side * side;
+        long long tcap = 6LL * nF / tiles + 512;
+        if (tcap > 16383) tcap = 16383;
+        if (a->force_bvh == 2) tcap = 64;              // diagnostic: force the subset-overflow fallback of the tiles
+        const unsigned long long slots = (unsigned long long)L * tiles * tcap;
+        if (slots * 6ull <= (32ull << 30)) {
+            rc = c->live.ensure(sizeof(uint16_t) * slots + 16);
+            if (!rc) rc = c->tile_list.ensure(sizeof(uint32_t) * slots + 16);
+            if (!rc) rc = c->tile_count.ensure(sizeof(int) * 2 * (size_t)L * tiles + 16);
+            if (rc) return rc;
+            fa.tile_count = c->tile_count.as<int>();
+            fa.live = c->live.as<uint16_t>();
+            fa.tile_list = c->tile_list.as<uint32_t>();
+            fa.tiles_x = fa.tiles_y = side;
+            fa.tile_cap = (int)tcap;
+        }
     }
 #ifdef NLOS_FWD_STAMPS
     HIP_TRY(hipMemsetAsync(c->status.p, 0, 64 * sizeof(int), st));
@@ -463,7 +490,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
 #endif
     fa.rows = nullptr;
     fa.vis2 = nullptr;
-    if (a->sensor && fa.live && nF <= 8191) {
+    if (a->sensor && fa.live && !fa.tile_list) {
         // sensor-leg visibility bits of the two-pass grid path for non-confocal pairs
         rc = c->vis2.ensure(sizeof(uint32_t) * (size_t)(L > 0 ? L : 1) * vis_words * nF + 16);
         if (rc) return rc;
@@ -524,6 +551,9 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         std::fprintf(stderr, "[fwd counters] rays %lld entries/source %.0f | scan: lane-it %.1f/ray, wave-it %.1f/ray-wave | queued %.2f/ray | exact rounds %.2f/ray-wave\n",
                      h[8], (double)h[13] / (double)(L > 0 ? L : 1), (double)h[9] / (double)(h[8] ? h[8] : 1), (double)h[10] / rw,
                      (double)h[11] / (double)(h[8] ? h[8] : 1), (double)h[12] / rw);
+        if (fa.tile_list)
+            std::fprintf(stderr, "[fwd tiles] %d x %d tiles, capacity %d: %lld overflowing tiles, largest subset %lld | entry overflow: %lld workgroups, most entries %lld\n",
+                         fa.tiles_x, fa.tiles_y, fa.tile_cap, h[22], h[23], h[20], h[21]);
     }
 #endif
     if (!skip_pass1 && mode != NLOS_MODE_INTENSITY && fwd_refine > 1) {

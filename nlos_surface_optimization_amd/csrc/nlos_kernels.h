@@ -75,6 +75,11 @@ struct ForwardArgs {
     long long* dbg;          // diagnostic builds only (NLOS_FWD_STAMPS); null in the product
     uint16_t* live;          // [L, F] scratch: per-source bucketed list of contributing faces (grid kernel)
     uint32_t* vis2;          // [L, vis_words, F] scratch: sensor-leg visibility of non-confocal pairs (grid path) or null
+    // tiled grid (meshes beyond one workgroup's LDS): slope space is cut into tiles_x * tiles_y tiles, one
+    // workgroup per (source, tile); tile_list holds each workgroup's triangle subset (tile_cap ids each)
+    uint32_t* tile_list;     // [L * tiles, tile_cap] scratch or null
+    int* tile_count;         // [2, L * tiles]: subset sizes (may exceed tile_cap: overflow) filled by k_tile_bin; retry flags
+    int tiles_x, tiles_y, tile_cap;
 };
 void launch_forward(const ForwardArgs& a, hipStream_t stream);
 

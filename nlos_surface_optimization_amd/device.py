@@ -114,7 +114,7 @@ class TransientRenderer:
         a.seed = self.seed if seed is None else int(seed)
         if alpha is not None:
             a.use_ggx, a.ggx_alpha = 1, float(alpha)
-        a.force_bvh = 1 if force_bvh else 0
+        a.force_bvh = int(force_bvh)       # False/0 default, True/1 BVH only, 2 diagnostic (tile overflow fallback)
         if sensor is not None:
             # row N: measurement l is the pair (laser origin[l], sensor[l]); default sensor wall normal = laser's
             if sensor_normal is None:

@@ -589,3 +589,35 @@ def test_config5_shape_ggx_poisson_noised_1024_bins(bunny, orc):
     assert rel_l2(tr, t_ref) <= 1e-5 and rel_l2(grad, g_ref) <= 1e-4
     ga = ggx.renderStreamedGradientAlpha(o, n, v, f, 0.3, ns, lb, ub, res, tr, path, data, w, 10, 1)
     assert abs(ga - a_ref) <= 1e-4 * abs(a_ref)
+
+
+def test_tiled_grid_for_large_meshes_agrees_with_bvh_and_oracle(bunny, orc):
+    """F = 19 868 (bunny_5k subdivided once): the grid is tiled over several workgroups per source.
+    Tiled grid == BVH back-end (same accept decisions), also when every tile overflows its subset
+    capacity (force_bvh=2 diagnostic) and for a source inside the scene's depth range (tile 0 alone);
+    rows and gradient vs the oracle on a few sources."""
+    import torch
+    from nlos_surface_optimization_amd import device as nd, mesh_io
+    v, f = bunny
+    v2, f2 = mesh_io.subdivide(v, f, 1)
+    assert f2.shape[0] == 4 * f.shape[0]
+    o, n = grid_sources(3, 0.22)
+    o[4, 2] = 0.45                                   # one wall point inside the scene's depth range
+    ns = 4 * f2.shape[0]                             # spt = 4
+    dev = torch.device("cuda", 0)
+    r = nd.TransientRenderer(dev, seed=4)
+    tv, tf_ = torch.from_numpy(v2).to(dev), torch.from_numpy(f2).to(dev)
+    to, tn = torch.from_numpy(o).to(dev), torch.from_numpy(n).to(dev)
+    t_tiled, _ = r.render_transient(to, tn, tv, tf_, ns, LB, UB, RES)
+    t_bvh, _ = r.render_transient(to, tn, tv, tf_, ns, LB, UB, RES, force_bvh=True)
+    t_over, _ = r.render_transient(to, tn, tv, tf_, ns, LB, UB, RES, force_bvh=2)
+    assert t_bvh.sum().item() > 0
+    assert (t_tiled - t_bvh).abs().max().item() <= 1e-13 * t_bvh.max().item()
+    assert (t_over - t_bvh).abs().max().item() <= 1e-13 * t_bvh.max().item()
+    t_ref, _ = orc.render_transient(o[:3], n[:3], v2, f2, ns, LB, UB, RES, accel=1, seed=4)
+    assert rel_l2(t_tiled[:3].cpu().numpy(), t_ref) <= 1e-12
+    data = t_tiled * 1.3
+    w = torch.ones_like(data)
+    _, g1, _ = r.render_gradient(to, tn, tv, tf_, ns, LB, UB, RES, data=data, weight=w)
+    _, g2, _ = r.render_gradient(to, tn, tv, tf_, ns, LB, UB, RES, data=data, weight=w, force_bvh=True)
+    assert rel_l2(g1.cpu().numpy(), g2.cpu().numpy()) <= 1e-6

@@ -15,9 +15,15 @@ import os
 d = np.load(os.path.join(os.environ["GRAFT_REPO_ROOT"], "tests/golden/bunny_5k.npz"))
 dev = torch.device("cuda", 0)
 r = nd.TransientRenderer(dev)
-v = torch.from_numpy(d["v"]).to(dev); f = torch.from_numpy(d["f"]).to(dev)
+vv, ff = d["v"], d["f"]
+sub = int(os.environ.get("NLOS_STAMP_SUBDIV", "0"))
+if sub:
+    from nlos_stamped import mesh_io
+    vv, ff = mesh_io.subdivide(vv, ff, sub)
+v = torch.from_numpy(vv).to(dev); f = torch.from_numpy(ff).to(dev)
+ns = 4 * ff.shape[0]
 g = torch.linspace(-0.25, 0.25, 32, device=dev); o = torch.stack([g.repeat(32), g.repeat_interleave(32), torch.zeros(1024, device=dev)], 1).contiguous(); n = torch.tensor([[0, 0, 1.0]] * 1024, device=dev)
 for _ in range(3):
-    r.render_transient(o, n, v, f, 20000, 0.625, 1.625, 2.0 ** -9)
+    r.render_transient(o, n, v, f, ns, 0.625, 1.625, 2.0 ** -9)
 torch.cuda.synchronize()
 PY
