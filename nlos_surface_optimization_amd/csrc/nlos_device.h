@@ -159,9 +159,15 @@ __device__ __forceinline__ bool box_test(float4 a, float4 b, const RayBox& r, fl
     float t0z = (a.z - r.oz) * r.iz, t1z = (b.y - r.oz) * r.iz;
     float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
     float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-    // widen by a few ulp: boxes are padded at build time, this covers the slab arithmetic
-    tn = tn - fabsf(tn) * 4e-7f;
-    tf = tf + fabsf(tf) * 4e-7f;
+    // widen the interval: boxes are padded at build time, this covers the slab arithmetic and -- partly --
+    // the error of t itself for triangles the ray meets at a grazing angle (t = T / den with den -> 0 is only
+    // as good as den; a box test that prunes by t can then disagree with the brute-force definition of the
+    // closest hit, see DESIGN.md section 2 "grazing occluders")
+#ifndef NLOS_BOX_EPS
+#define NLOS_BOX_EPS 1e-4f
+#endif
+    tn = tn - fabsf(tn) * NLOS_BOX_EPS;
+    tf = tf + fabsf(tf) * NLOS_BOX_EPS;
     return fmaxf(tn, 0.0f) <= fminf(tf, tmax);
 }
 

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep: GPU (all occlusion back-ends) vs the CPU oracle on random meshes, sources,
+windows and sample counts.  The accept/reject decisions must be identical, so the forward rows agree
+to fp64 summation order (~1e-15; the sweep tolerates 1e-9, i.e. one grazing-occluder sample, DESIGN.md
+section 2); gradient 1e-4.  Usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle as orc  # noqa: E402
+from nlos_surface_optimization_amd import mesh_io, renderer  # noqa: E402
+
+
+def rel_l2(a, b):
+    d = np.linalg.norm(b)
+    return float(np.linalg.norm(a - b) / d) if d > 0 else float(np.linalg.norm(a - b))
+
+
+def random_mesh(rs):
+    kind = rs.randint(0, 4)
+    if kind == 0:      # noisy height field (open sheet), wall-facing
+        n = rs.randint(6, 60)
+        xs, ys = np.meshgrid(np.linspace(-0.3, 0.3, n), np.linspace(-0.3, 0.3, n))
+        z = 0.45 + 0.08 * np.sin(7 * xs + rs.rand()) * np.cos(5 * ys) + rs.normal(0, rs.choice([0.0, 0.004, 0.02]), xs.shape)
+        v = np.stack([xs.ravel(), ys.ravel(), z.ravel()], 1)
+        idx = np.arange(n * n).reshape(n, n)
+        a, b, c, d = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, 1:].ravel(), idx[1:, :-1].ravel()
+        f = np.concatenate([np.stack([a, c, b], 1), np.stack([a, d, c], 1)])
+    elif kind == 1:    # bunny, randomly scaled / shifted / subdivided
+        d = np.load(os.path.join(ROOT, "tests", "golden", "bunny_5k.npz"))
+        v, f = d["v"].astype(np.float64), d["f"]
+        if rs.rand() < 0.3:
+            keep = rs.rand(f.shape[0]) < rs.uniform(0.05, 0.9)
+            f = f[keep]
+        v = (v - v.mean(0)) * rs.uniform(0.5, 1.5) + np.array([rs.uniform(-0.1, 0.1), rs.uniform(-0.1, 0.1), rs.uniform(0.4, 0.6)])
+        if rs.rand() < 0.25:
+            v, f = mesh_io.subdivide(v.astype(np.float32), f, 1)          # ~20k faces: tiled grid
+    elif kind == 2:    # triangle soup: random sizes and orientations, heavy occlusion
+        m = rs.randint(64, 3000)
+        c = np.stack([rs.uniform(-0.3, 0.3, m), rs.uniform(-0.3, 0.3, m), rs.uniform(0.3, 0.7, m)], 1)
+        s = rs.choice([0.01, 0.05, 0.2]) * rs.rand(m, 1, 1)
+        tri = c[:, None, :] + s * rs.normal(size=(m, 3, 3))
+        v = tri.reshape(-1, 3)
+        f = np.arange(3 * m).reshape(m, 3)
+    else:              # sphere with an inner sphere (closed surfaces, depth layers)
+        def sph(r, cz, n):
+            th, ph = np.meshgrid(np.linspace(0.05, np.pi - 0.05, n), np.linspace(0, 2 * np.pi, 2 * n, endpoint=False), indexing="ij")
+            vv = np.stack([r * np.sin(th) * np.cos(ph), r * np.sin(th) * np.sin(ph), cz + r * np.cos(th)], -1).reshape(-1, 3)
+            idx = np.arange(n * 2 * n).reshape(n, 2 * n)
+            a, b = idx[:-1, :], np.roll(idx[:-1, :], -1, 1)
+            c, d = np.roll(idx[1:, :], -1, 1), idx[1:, :]
+            ff = np.concatenate([np.stack([a.ravel(), b.ravel(), c.ravel()], 1), np.stack([a.ravel(), c.ravel(), d.ravel()], 1)])
+            return vv, ff
+        n = rs.randint(5, 30)
+        v1, f1 = sph(0.15, 0.5, n)
+        v2, f2 = sph(0.07, 0.42, max(4, n // 2))
+        v = np.concatenate([v1, v2])
+        f = np.concatenate([f1, f2 + v1.shape[0]])
+    if rs.rand() < 0.5:
+        f = f[:, [0, 2, 1]]
+    return np.ascontiguousarray(v, np.float32), np.ascontiguousarray(f, np.int32)
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    import torch
+    from nlos_surface_optimization_amd import device as nd
+    dev = torch.device("cuda", 0)
+    worst_t, worst_g, bad = 0.0, 0.0, 0
+    for case in range(n_cases):
+        rs = np.random.RandomState(seed * 100003 + case)
+        v, f = random_mesh(rs)
+        F = f.shape[0]
+        L = rs.randint(1, 6)
+        o = np.zeros((L, 3), np.float32)
+        o[:, :2] = rs.uniform(-0.6, 0.6, (L, 2))
+        if rs.rand() < 0.15:
+            o[0, 2] = rs.uniform(0.3, 0.6)            # a wall point inside the scene's depth range
+        nrm = np.tile(np.array([0, 0, 1], np.float32), (L, 1))
+        spt = int(rs.choice([1, 2, 5, 9, 33]))
+        ns = spt * F - rs.randint(0, F)
+        ns = max(ns, 1)
+        T = int(rs.choice([64, 512, 1000]))
+        res = float(np.float32(rs.choice([2.0 ** -9, 2.0 ** -7, 1.2e-3, 5e-3])))
+        # mostly windows that contain (part of) the object, sometimes one that misses it
+        dmin = 2 * float(np.min(np.linalg.norm(v[None, ::7, :] - o[:, None, :], axis=2)))
+        lb = float(np.float32(max(0.0, dmin + rs.uniform(-0.5, 0.3) * T * res))) if rs.rand() < 0.85 else float(np.float32(rs.uniform(0.0, 0.8)))
+        ub = float(np.float32(np.float32(lb) + np.float32(T) * np.float32(res)))
+        use_vn = rs.rand() < 0.25
+        vn = None
+        if use_vn:
+            from conftest import vertex_normals
+            vn = vertex_normals(v, f)
+        kw = dict(accel=1, seed=case, vnormal=vn)
+        t_ref, _ = orc.render_transient(o, nrm, v, f, ns, lb, ub, res, **kw)
+        r = nd.TransientRenderer(dev, seed=case)
+        tv, tf_, to, tn = (torch.from_numpy(x).to(dev) for x in (v, f, o, nrm))
+        tvn = None if vn is None else torch.from_numpy(vn).to(dev)
+        errs = []
+        for fb in (0, 1) + ((2,) if F > 7400 else ()):
+            t, _ = r.render_transient(to, tn, tv, tf_, ns, lb, ub, res, vertex_normal=tvn, force_bvh=fb)
+            errs.append(rel_l2(t.cpu().numpy(), t_ref))
+        et = max(errs)
+        eg = 0.0
+        if t_ref.sum() > 0 and rs.rand() < 0.6:
+            data = t_ref * (1 + 0.3 * rs.standard_normal(t_ref.shape))
+            w = 0.5 + rs.random_sample(t_ref.shape)
+            sb = int(rs.choice([1, 1, 2, 5]))
+            rf = int(rs.choice([4, 10]))
+            _, g_ref, _ = orc.render_gradient(o, nrm, v, f, ns, lb, ub, res, data, w, refine=rf, sigma_bin=sb,
+                                              testing_flag=int(rs.randint(0, 2)), **kw)
+            tf0 = 0
+            _, g_ref, _ = orc.render_gradient(o, nrm, v, f, ns, lb, ub, res, data, w, refine=rf, sigma_bin=sb,
+                                              testing_flag=tf0, **kw)
+            _, g, _ = r.render_gradient(to, tn, tv, tf_, ns, lb, ub, res, data=torch.from_numpy(data).to(dev),
+                                        weight=torch.from_numpy(w).to(dev), refine_scale=rf, sigma_bin=sb,
+                                        testing_flag=tf0, vertex_normal=tvn)
+            if np.abs(g_ref).max() > 0:
+                eg = rel_l2(g.cpu().numpy(), g_ref)
+        r.close()
+        ok = et <= 1e-9 and eg <= 1e-4          # 1e-9: one grazing-occluder sample at most
+        if not ok and t_ref.sum() > 0:
+            bad += 1
+        worst_t, worst_g = max(worst_t, et), max(worst_g, eg)
+        print("case %3d F=%6d L=%d spt=%2d T=%4d vn=%d sum=%.3e  transient %.2e (grid/bvh%s)  gradient %.2e %s" % (
+            case, F, L, spt, T, int(use_vn), t_ref.sum(), et, "/ovf" if F > 7400 else "", eg, "" if ok else "  <-- MISMATCH"),
+            flush=True)
+    print("worst transient %.3e, worst gradient %.3e, mismatches %d / %d" % (worst_t, worst_g, bad, n_cases))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
