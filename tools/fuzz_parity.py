@@ -123,13 +123,24 @@ def main():
                                         testing_flag=tf0, vertex_normal=tvn)
             if np.abs(g_ref).max() > 0:
                 eg = rel_l2(g.cpu().numpy(), g_ref)
+        en = 0.0
+        if rs.rand() < 0.35 and not use_vn:
+            # row N: random sensor point per laser, both back-ends
+            b = o.copy()
+            b[:, :2] += rs.uniform(-0.3, 0.3, (L, 2)).astype(np.float32)
+            tn_ref, _, _ = orc.render_nonconfocal(o, nrm, b, nrm, v, f, ns, lb, ub, res, refine=1, accel=1, seed=case)
+            tb = torch.from_numpy(b).to(dev)
+            for fb in (0, 1):
+                t, _ = r.render_transient(to, tn, tv, tf_, ns, lb, ub, res, sensor=tb, sensor_normal=tn, force_bvh=fb)
+                en = max(en, rel_l2(t.cpu().numpy(), tn_ref))
+            et = max(et, en)
         r.close()
         ok = et <= 1e-9 and eg <= 1e-4          # 1e-9: one grazing-occluder sample at most
         if not ok and t_ref.sum() > 0:
             bad += 1
         worst_t, worst_g = max(worst_t, et), max(worst_g, eg)
-        print("case %3d F=%6d L=%d spt=%2d T=%4d vn=%d sum=%.3e  transient %.2e (grid/bvh%s)  gradient %.2e %s" % (
-            case, F, L, spt, T, int(use_vn), t_ref.sum(), et, "/ovf" if F > 7400 else "", eg, "" if ok else "  <-- MISMATCH"),
+        print("case %3d F=%6d L=%d spt=%2d T=%4d vn=%d sum=%.3e  transient %.2e (grid/bvh%s)  gradient %.2e  nc %.2e %s" % (
+            case, F, L, spt, T, int(use_vn), t_ref.sum(), et, "/ovf" if F > 7400 else "", eg, en, "" if ok else "  <-- MISMATCH"),
             flush=True)
     print("worst transient %.3e, worst gradient %.3e, mismatches %d / %d" % (worst_t, worst_g, bad, n_cases))
     return 1 if bad else 0
