@@ -1615,6 +1615,145 @@ __global__ __launch_bounds__(NLOS_GRAD_NT, NLOS_GRAD_WPS) void k_gradient(Gradie
     }
 }
 
+// ------------------------------------------------- gradient, large meshes (face-major)
+// When 3V doubles do not fit LDS, k_gradient above falls back to nine global atomics per (source, face)
+// pair -- 74 M of them per step at F = 20 k, executed memory-side across the eight XCDs (4.7 ms).  This
+// variant turns the loop nest around: a workgroup owns a CHUNK of kFmChunk consecutive (Morton-sorted)
+// faces and a group of sources, keeps the nine sums of every face of the chunk in LDS across all its
+// sources (ds_add_f64, one writer lane per item), and touches the vertex gradient only once per face at
+// the end.  Per batch of kFmBatch sources it loads the residual rows, compacts the (source, face) items
+// with accepted samples into an LDS list (ballot + one LDS counter) and hands them to the lanes densely.
+// Same per-sample arithmetic as k_gradient<FEAT, 0>; only the fp64 summation order differs.
+constexpr int kFmChunk = 512, kFmBatch = 4, kFmThreads = 256;
+
+template <int FEAT>
+__global__ __launch_bounds__(kFmThreads) void k_gradient_fm(GradientArgs a, int src_per_group) {
+    extern __shared__ double s_fm[];      // [acc 9*CHUNK][rows BATCH*T][delta K][p0 K+1][p1 K+1][list BATCH*CHUNK u16][ctl]
+    const int T = a.sp.nbins, K = a.K, F = a.sc.F;
+    double* s_acc = s_fm;
+    double* s_rows = s_acc + 9 * kFmChunk;
+    double* s_delta = s_rows + kFmBatch * T;
+    double* s_p0 = s_delta + K;
+    double* s_p1 = s_p0 + K + 1;
+    uint16_t* s_list = reinterpret_cast<uint16_t*>(s_p1 + K + 1);
+    int* s_cnt = reinterpret_cast<int*>(s_list + kFmBatch * kFmChunk);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int f0 = blockIdx.x * kFmChunk, nf = min(kFmChunk, F - f0);
+    const int l0 = blockIdx.y * src_per_group, l1 = min(l0 + src_per_group, a.src.L);
+    const int spt = a.sp.spt;
+    const int Ltot = a.src.total_sources > 0 ? a.src.total_sources : a.src.L;
+    const double lbd = (double)a.sp.lb, resd = (double)a.sp.res, inv_res = 1.0 / resd;
+    for (int i = tid; i < 9 * kFmChunk; i += kFmThreads) s_acc[i] = 0.0;
+    for (int i = tid; i < K; i += kFmThreads) s_delta[i] = a.tap_delta[i];
+    for (int i = tid; i <= K; i += kFmThreads) { s_p0[i] = a.tap_p0[i]; s_p1[i] = a.tap_p1[i]; }
+    TapTables tt;
+    tt.delta = s_delta; tt.p0 = s_p0; tt.p1 = s_p1; tt.K = K; tt.two_rs = a.two_rs; tt.r_over_res = a.r_over_res;
+
+    for (int lb0 = l0; lb0 < l1; lb0 += kFmBatch) {
+        const int nb = min(kFmBatch, l1 - lb0);
+        __syncthreads();                                   // previous batch done with rows / list
+        for (int i = tid; i < nb * T; i += kFmThreads) s_rows[i] = a.diff[(size_t)lb0 * T + i];
+        if (tid == 0) *s_cnt = 0;
+        __syncthreads();
+        // (source, face) items of this batch with at least one accepted sample
+        for (int it = tid; it < nb * kFmChunk; it += kFmThreads) {
+            const int bl = it / kFmChunk, jl = it - bl * kFmChunk;
+            uint32_t any = 0;
+            if (jl < nf) {
+                const uint32_t* visp = a.vis + ((size_t)(lb0 + bl) * a.vis_words) * F + f0 + jl;
+                for (int wi = 0; wi < a.vis_words; ++wi) any |= visp[(size_t)wi * F];
+            }
+            const unsigned long long m = __ballot(any != 0u);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(s_cnt, __popcll(m));
+            base = __shfl(base, 0);
+            if (any) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((bl << 12) | jl);
+        }
+        __syncthreads();
+        const int n_items = *s_cnt;
+        for (int it = tid; it < n_items; it += kFmThreads) {
+            const int code = s_list[it];
+            const int bl = code >> 12, jl = code & 0xFFF;
+            const int l = lb0 + bl, j = f0 + jl;
+            const double* s_diff = s_rows + bl * T;
+            const Face f = load_face(a.sc.facerec, j);
+            const Tri tr = load_tri(a.sc.tris, j);
+            const V3 o = ld3(a.src.origin + 3 * (size_t)l);
+            const V3 on = ld3(a.src.normal + 3 * (size_t)l);
+            const uint64_t kbase = ((uint64_t)(a.src.source_offset + l) * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
+            const uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
+            double acc[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) acc[q] = 0.0;
+            for (int wi = 0; wi < a.vis_words; ++wi) {
+                uint32_t word = visp[(size_t)wi * F];
+                while (word) {
+                    const int bit = __ffs(word) - 1;
+                    word &= word - 1;
+                    Geo g;
+                    float t_self;
+                    if (!sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)((wi << 5) + bit), a.sp.lb, a.sp.ub,
+                                          a.sc.vertex_normal, a.sc.albedo, g, t_self))
+                        continue;
+                    GVec gv;
+                    grad_vectors<FEAT>(f, g, on, a.normal_term, a.v1_style, a.sp.ggx_alpha, gv);
+                    const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
+                    const V3 ce[3] = {cross(gv.t2, e0), cross(gv.t2, e1), cross(gv.t2, e2)};
+                    double s0, s1;
+                    grouped_taps(tt, s_diff, T, (double)(2.0f * g.h), lbd, resd, inv_res, s0, s1);
+                    const V3 di = g.dir * gv.inten_f;
+                    const float bw[3] = {g.u, g.v, g.w};
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const V3 A1 = gv.t1 * bw[q] + ce[q];
+                        const V3 A2 = di * bw[q];
+                        acc[3 * q + 0] += (double)A1.x * s0 + (double)A2.x * s1;
+                        acc[3 * q + 1] += (double)A1.y * s0 + (double)A2.y * s1;
+                        acc[3 * q + 2] += (double)A1.z * s0 + (double)A2.z * s1;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q) unsafeAtomicAdd(&s_acc[9 * jl + q], acc[q]);
+        }
+    }
+    __syncthreads();
+    // one pass over the chunk: scale and scatter to the vertices
+    for (int jl = tid; jl < nf; jl += kFmThreads) {
+        const Face f = load_face(a.sc.facerec, f0 + jl);
+        if (f.degenerate) continue;
+        const double sc = (double)f.area / (double)spt / (double)Ltot;
+        const int vi[3] = {f.i0, f.i1, f.i2};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double val = s_acc[9 * jl + 3 * q + c];
+                if (val != 0.0) unsafeAtomicAdd(&a.out[3 * (size_t)vi[q] + c], val * sc);
+            }
+    }
+}
+
+template <int FEAT>
+bool gradient_fm_launch(const GradientArgs& a, hipStream_t stream) {
+    // only the plain vertex gradient of meshes whose 3V accumulator cannot live in LDS
+    if (a.mode != 0 || a.src.sensor || a.sp.nbins * kFmBatch > 8192) return false;
+    const size_t lds = ((size_t)9 * kFmChunk + (size_t)kFmBatch * a.sp.nbins + 3 * (size_t)a.K + 2) * sizeof(double) +
+                       (size_t)kFmBatch * kFmChunk * 2 + 16;
+    if (lds > 80 * 1024) return false;
+    const int nchunks = (a.sc.F + kFmChunk - 1) / kFmChunk;
+    // enough workgroups to fill the chip (256 CUs x 2), sources in multiples of the batch
+    int groups = (1024 + nchunks - 1) / nchunks;
+    int per = (a.src.L + groups - 1) / groups;
+    per = ((per + kFmBatch - 1) / kFmBatch) * kFmBatch;
+    if (per < kFmBatch) per = kFmBatch;
+    groups = (a.src.L + per - 1) / per;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient_fm<FEAT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient_fm<FEAT>), dim3(nchunks, groups), dim3(kFmThreads), lds, stream, a, per);
+    return true;
+}
+
 // ------------------------------------------------------------------ intersect
 __global__ __launch_bounds__(256) void k_intersect(IntersectArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1814,6 +1953,21 @@ void launch_gradient(const GradientArgs& a_in, hipStream_t stream) {
     // per-workgroup 3V-double accumulator while it fits beside the rest (one workgroup per CU at worst)
     const size_t acc = 3 * (size_t)a.sc.V * sizeof(double);
     a.lds_grad = ((a.mode == 0 || a.mode == 4) && a_in.lds_grad && lds + acc <= 150 * 1024) ? 1 : 0;
+    if (!a.lds_grad && a.mode == 0 && !a.src.sensor && a_in.lds_grad) {
+        // large meshes: face-major variant (per-face sums in LDS across sources, one scatter per face)
+        bool done = false;
+        switch (feat_of(a.sc, a.sp)) {
+            case 0: done = gradient_fm_launch<0>(a, stream); break;
+            case 1: done = gradient_fm_launch<1>(a, stream); break;
+            case 2: done = gradient_fm_launch<2>(a, stream); break;
+            case 3: done = gradient_fm_launch<3>(a, stream); break;
+            case 4: done = gradient_fm_launch<4>(a, stream); break;
+            case 5: done = gradient_fm_launch<5>(a, stream); break;
+            case 6: done = gradient_fm_launch<6>(a, stream); break;
+            default: done = gradient_fm_launch<7>(a, stream); break;
+        }
+        if (done) return;
+    }
     if (a.lds_grad) lds += acc;
     // persistent workgroups: as many as can be co-resident (512 threads each, <= 128 VGPRs -> 4 per CU)
     int per_cu = (int)(160 * 1024 / (lds + 64));

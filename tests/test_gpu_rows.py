@@ -621,3 +621,9 @@ def test_tiled_grid_for_large_meshes_agrees_with_bvh_and_oracle(bunny, orc):
     _, g1, _ = r.render_gradient(to, tn, tv, tf_, ns, LB, UB, RES, data=data, weight=w)
     _, g2, _ = r.render_gradient(to, tn, tv, tf_, ns, LB, UB, RES, data=data, weight=w, force_bvh=True)
     assert rel_l2(g1.cpu().numpy(), g2.cpu().numpy()) <= 1e-6
+    # V = 9.8 k: the 3V-double accumulator does not fit LDS -> face-major gradient kernel; against the oracle
+    d3 = data[:3].cpu().numpy()
+    _, g_ref, _ = orc.render_gradient(o[:3], n[:3], v2, f2, ns, LB, UB, RES, d3, np.ones_like(d3), accel=1, seed=4)
+    _, g3, _ = r.render_gradient(to[:3].contiguous(), tn[:3].contiguous(), tv, tf_, ns, LB, UB, RES,
+                                 data=data[:3].contiguous(), weight=w[:3].contiguous())
+    assert np.abs(g_ref).max() > 0 and rel_l2(g3.cpu().numpy(), g_ref) <= 1e-4
