@@ -64,9 +64,123 @@ __device__ __forceinline__ void emit_node(const BuildArgs& a, int id, const floa
     a.nodes[2 * id + 1] = make_float4(b[4], b[5], __int_as_float(esc), __int_as_float(link));
 }
 
+// Karras (2012) radix-tree node i over the sorted keys: children, covered leaf range, parent links
+__device__ __forceinline__ void karras_node(const BuildArgs& a, const uint32_t* __restrict__ keys, int F, int i,
+                                            int& left, int& right) {
+    const int n_int = F - 1;
+    int d = (delta(keys, F, i, i + 1) - delta(keys, F, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = delta(keys, F, i, i - d);
+    int lmax = 2;
+    while (delta(keys, F, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(keys, F, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = delta(keys, F, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(keys, F, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    int gamma = i + s * d + min(d, 0);
+    int first = min(i, j), last = max(i, j);
+    left = (first == gamma) ? (n_int + gamma) : gamma;
+    right = (last == gamma + 1) ? (n_int + gamma + 1) : (gamma + 1);
+    a.child[2 * i] = left;
+    a.child[2 * i + 1] = right;
+    a.range[2 * i] = first;
+    a.range[2 * i + 1] = last;
+    a.parent[left] = i;
+    a.parent[right] = i;
+    a.arrive[i] = 0;
+}
+
+// escape link of the node covering leaves [.., last]
+__device__ __forceinline__ int escape_link(const BuildArgs& a, int F, int last) {
+    const int n_int = F - 1;
+    const int s = last + 1;
+    if (s >= F) return -1;
+    if (s < n_int && a.range[2 * s] == s) return s;      // inner node s starts at leaf s
+    return n_int + s;                                    // otherwise the leaf itself
+}
+
+// triangle / face records of sorted slot j and its padded box
+__device__ __forceinline__ void leaf_records(const BuildArgs& a, const int* __restrict__ order, int j, float pad,
+                                             float (&lb6)[6]) {
+    int f = order[j];
+    int i0 = clamp_index(a.faces[3 * f], a.V, a.status);
+    int i1 = clamp_index(a.faces[3 * f + 1], a.V, a.status);
+    int i2 = clamp_index(a.faces[3 * f + 2], a.V, a.status);
+    V3 p0 = ld3(a.vertices + 3 * (size_t)i0);
+    V3 p1 = ld3(a.vertices + 3 * (size_t)i1);
+    V3 p2 = ld3(a.vertices + 3 * (size_t)i2);
+    Tri tr = make_tri(p0, p1, p2);
+    a.tris[kTriStride * j] = make_float4(tr.p0.x, tr.p0.y, tr.p0.z, tr.e1.x);
+    a.tris[kTriStride * j + 1] = make_float4(tr.e1.y, tr.e1.z, tr.e2.x, tr.e2.y);
+    a.tris[kTriStride * j + 2] = make_float4(tr.e2.z, tr.ng.x, tr.ng.y, tr.ng.z);
+    a.tris[kTriStride * j + 3] = make_float4(fminf(fminf(p0.z, p1.z), p2.z), __int_as_float(f), 0.0f, 0.0f);
+    a.facerec[4 * j] = make_float4(p0.x, p0.y, p0.z, p1.x);
+    a.facerec[4 * j + 1] = make_float4(p1.y, p1.z, p2.x, p2.y);
+    a.facerec[4 * j + 2] = make_float4(p2.z, __int_as_float(f), __int_as_float(i0), __int_as_float(i1));
+    a.facerec[4 * j + 3] = make_float4(__int_as_float(i2), 0.0f, 0.0f, 0.0f);
+    a.face_id[j] = f;
+    a.tri_zmin[j] = fminf(fminf(p0.z, p1.z), p2.z);
+    lb6[0] = fminf(fminf(p0.x, p1.x), p2.x) - pad;
+    lb6[1] = fminf(fminf(p0.y, p1.y), p2.y) - pad;
+    lb6[2] = fminf(fminf(p0.z, p1.z), p2.z) - pad;
+    lb6[3] = fmaxf(fmaxf(p0.x, p1.x), p2.x) + pad;
+    lb6[4] = fmaxf(fmaxf(p0.y, p1.y), p2.y) + pad;
+    lb6[5] = fmaxf(fmaxf(p0.z, p1.z), p2.z) + pad;
+}
+
 }  // namespace
 
-__global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words) {
+// Large meshes (inner nodes beyond the LDS refit): the single workgroup stops after the sort and two
+// chip-wide launches finish the job -- the tree (one thread per inner node) and the refit (one thread per
+// leaf; the bottom-up walk is then as long as the deepest chain, ~35 levels, instead of F/1024 walks per
+// thread: 8.6 M cycles -> ~0.1 ms at F = 79 k).
+__global__ __launch_bounds__(256) void k_build_tree(BuildArgs a) {
+    const int F = a.F, n_int = F - 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) a.parent[F > 1 ? 0 : n_int] = -1;
+    if (i >= n_int) return;
+    int left, right;
+    karras_node(a, a.keys0, F, i, left, right);
+}
+
+__global__ __launch_bounds__(256) void k_build_refit(BuildArgs a) {
+    const int F = a.F, n_int = F - 1;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= F) return;
+    const float pad = a.box[6 * (size_t)(2 * F - 1)];      // left there by k_build_bvh
+    float lb6[6];
+    leaf_records(a, a.idx0, j, pad, lb6);
+    emit_node(a, n_int + j, lb6, escape_link(a, F, j), ~j);
+    float* b = a.box + 6 * (size_t)(n_int + j);
+    for (int c = 0; c < 6; ++c) b[c] = lb6[c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    int node = a.parent[n_int + j];
+    while (node >= 0) {
+        int old = atomicAdd(&a.arrive[node], 1);
+        if (old == 0) break;                   // sibling subtree not finished yet
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const float* bl = a.box + 6 * (size_t)a.child[2 * node];
+        const float* br = a.box + 6 * (size_t)a.child[2 * node + 1];
+        float* bo = a.box + 6 * (size_t)node;
+        float nb[6];
+        for (int c = 0; c < 6; ++c) {
+            float x = __hip_atomic_load(bl + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float y = __hip_atomic_load(br + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nb[c] = c < 3 ? fminf(x, y) : fmaxf(x, y);
+            __hip_atomic_store(bo + c, nb[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        emit_node(a, node, nb, escape_link(a, F, a.range[2 * node + 1]), a.child[2 * node]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        node = a.parent[node];
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, int split) {
     extern __shared__ uint32_t s_dyn[];       // radix counters [RDIG * BT] (128 KB)
     __shared__ uint32_t s_wsum[BT / 64];
     __shared__ float s_red[6 * 16];           // per-wave bounds
@@ -188,9 +302,13 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words) 
         uint32_t* tk = keys_in; keys_in = keys_out; keys_out = tk;
         int* ti = idx_in; idx_in = idx_out; idx_out = ti;
     }
-    const uint32_t* keys = keys_in;
+    const uint32_t* keys = keys_in;           // == a.keys0 / a.idx0 (even number of passes)
     const int* order = idx_in;
     NLOS_STAMP();
+    if (split) {
+        if (tid == 0) a.box[6 * (size_t)(2 * F - 1)] = pad;      // for k_build_refit
+        return;
+    }
 
     // ---- phase 4: Karras radix tree ------------------------------------------------
     const int n_int = F - 1;
@@ -209,31 +327,8 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words) 
         __syncthreads();
     }
     for (int i = tid; i < n_int; i += BT) {
-        int d = (delta(keys, F, i, i + 1) - delta(keys, F, i, i - 1)) >= 0 ? 1 : -1;
-        int dmin = delta(keys, F, i, i - d);
-        int lmax = 2;
-        while (delta(keys, F, i, i + lmax * d) > dmin) lmax <<= 1;
-        int l = 0;
-        for (int t = lmax >> 1; t >= 1; t >>= 1)
-            if (delta(keys, F, i, i + (l + t) * d) > dmin) l += t;
-        int j = i + l * d;
-        int dnode = delta(keys, F, i, j);
-        int s = 0, t = l;
-        do {
-            t = (t + 1) >> 1;
-            if (delta(keys, F, i, i + (s + t) * d) > dnode) s += t;
-        } while (t > 1);
-        int gamma = i + s * d + min(d, 0);
-        int first = min(i, j), last = max(i, j);
-        int left = (first == gamma) ? (n_int + gamma) : gamma;
-        int right = (last == gamma + 1) ? (n_int + gamma + 1) : (gamma + 1);
-        a.child[2 * i] = left;
-        a.child[2 * i + 1] = right;
-        a.range[2 * i] = first;
-        a.range[2 * i + 1] = last;
-        a.parent[left] = i;
-        a.parent[right] = i;
-        a.arrive[i] = 0;
+        int left, right;
+        karras_node(a, keys, F, i, left, right);
         if (lds_refit) {
             if (left < n_int) s_par[left] = (uint32_t)i;
             if (right < n_int) s_par[right] = (uint32_t)i;
@@ -243,41 +338,12 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words) 
     __syncthreads();
     NLOS_STAMP();
 
-    // escape link of the node covering leaves [first, last]
-    auto escape_of = [&](int last) -> int {
-        const int s = last + 1;
-        if (s >= F) return -1;
-        if (s < n_int && a.range[2 * s] == s) return s;      // inner node s starts at leaf s
-        return n_int + s;                                    // otherwise the leaf itself
-    };
+    auto escape_of = [&](int last) -> int { return escape_link(a, F, last); };
 
     // ---- phase 5: leaf records + bottom-up refit + node emission -------------------------
     for (int j = tid; j < F; j += BT) {
-        int f = order[j];
-        int i0 = clamp_index(a.faces[3 * f], a.V, a.status);
-        int i1 = clamp_index(a.faces[3 * f + 1], a.V, a.status);
-        int i2 = clamp_index(a.faces[3 * f + 2], a.V, a.status);
-        V3 p0 = ld3(a.vertices + 3 * (size_t)i0);
-        V3 p1 = ld3(a.vertices + 3 * (size_t)i1);
-        V3 p2 = ld3(a.vertices + 3 * (size_t)i2);
-        Tri tr = make_tri(p0, p1, p2);
-        a.tris[kTriStride * j] = make_float4(tr.p0.x, tr.p0.y, tr.p0.z, tr.e1.x);
-        a.tris[kTriStride * j + 1] = make_float4(tr.e1.y, tr.e1.z, tr.e2.x, tr.e2.y);
-        a.tris[kTriStride * j + 2] = make_float4(tr.e2.z, tr.ng.x, tr.ng.y, tr.ng.z);
-        a.tris[kTriStride * j + 3] = make_float4(fminf(fminf(p0.z, p1.z), p2.z), __int_as_float(f), 0.0f, 0.0f);
-        a.facerec[4 * j] = make_float4(p0.x, p0.y, p0.z, p1.x);
-        a.facerec[4 * j + 1] = make_float4(p1.y, p1.z, p2.x, p2.y);
-        a.facerec[4 * j + 2] = make_float4(p2.z, __int_as_float(f), __int_as_float(i0), __int_as_float(i1));
-        a.facerec[4 * j + 3] = make_float4(__int_as_float(i2), 0.0f, 0.0f, 0.0f);
-        a.face_id[j] = f;
-        a.tri_zmin[j] = fminf(fminf(p0.z, p1.z), p2.z);
         float lb6[6];
-        lb6[0] = fminf(fminf(p0.x, p1.x), p2.x) - pad;
-        lb6[1] = fminf(fminf(p0.y, p1.y), p2.y) - pad;
-        lb6[2] = fminf(fminf(p0.z, p1.z), p2.z) - pad;
-        lb6[3] = fmaxf(fmaxf(p0.x, p1.x), p2.x) + pad;
-        lb6[4] = fmaxf(fmaxf(p0.y, p1.y), p2.y) + pad;
-        lb6[5] = fmaxf(fmaxf(p0.z, p1.z), p2.z) + pad;
+        leaf_records(a, order, j, pad, lb6);
         emit_node(a, n_int + j, lb6, escape_of(j), ~j);
         if (lds_refit) {
             // merge into the parent's box with LDS min/max atomics, then raise the parent's flag; the
@@ -342,9 +408,14 @@ void launch_build_bvh(const BuildArgs& a, hipStream_t stream) {
     const size_t refit = 7 * sizeof(uint32_t) * (size_t)(a.F > 1 ? a.F - 1 : 0);
     const size_t lds_max = 160 * 1024 - 1024;
     if (refit > lds && refit <= lds_max) lds = refit;
+    const int split = (refit > lds_max && a.F > 1) ? 1 : 0;      // tree + refit as chip-wide launches
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_bvh), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    hipLaunchKernelGGL(k_build_bvh, dim3(1), dim3(BT), lds, stream, a, (int)(lds / sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_build_bvh, dim3(1), dim3(BT), lds, stream, a, (int)(lds / sizeof(uint32_t)), split);
+    if (split) {
+        hipLaunchKernelGGL(k_build_tree, dim3((a.F + 255) / 256), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_build_refit, dim3((a.F + 255) / 256), dim3(256), 0, stream, a);
+    }
 }
 
 }  // namespace nlos

@@ -188,7 +188,7 @@ int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bo
     rc |= c->range.ensure(sizeof(int) * 2 * (size_t)nF);
     rc |= c->parent.ensure(sizeof(int) * n_nodes);
     rc |= c->arrive.ensure(sizeof(int) * (size_t)nF);
-    rc |= c->box.ensure(sizeof(float) * 6 * n_nodes);
+    rc |= c->box.ensure(sizeof(float) * (6 * n_nodes + 8));      // + the box padding handed to k_build_refit
     rc |= c->status.ensure(sizeof(int) * 64);
     rc |= c->nodes.ensure(sizeof(float4) * 2 * n_nodes);
     rc |= c->tris.ensure(sizeof(float4) * 4 * (size_t)nF);

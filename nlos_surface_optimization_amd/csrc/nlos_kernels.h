@@ -17,7 +17,7 @@ struct BuildArgs {
     int* range;              // [2*(F-1)]
     int* parent;             // [2F-1]
     int* arrive;             // [F-1]
-    float* box;              // [6*(2F-1)]
+    float* box;              // [6*(2F-1) + 8]
     int* status;             // [1] bit0: face index out of range
     // outputs
     float4* nodes;           // [2*(2F-1)]  pre-order, 32 B per node
