@@ -1,0 +1,810 @@
+// forward_grid.hip -- pass 1 through the per-source perspective grid (gfx950): the fast path.
+//
+//   k_forward_grid<FEAT, NCM, TILED>  one workgroup per source (or per (source, slope-space tile) for
+//                                     meshes beyond one workgroup's LDS); NCM = the two passes of a
+//                                     non-confocal pair
+//   k_tile_bin                        triangle -> tile subsets for the tiled variant
+// Same samples, same accept/reject decisions as forward_bvh.hip (smoothed_transient/
+// transient_and_gradient.cpp:122-237); only the "is anything in front of this ray" query differs.
+#include "render_common.h"
+
+namespace nlos {
+namespace {
+
+// ------------------------------------------------------------- forward (grid)
+// Per-source perspective grid.  Every ray of a workgroup starts at the same wall point o, so the
+// triangles that can block the ray towards slope (mx, my) = (dx/dz, dy/dz) are exactly those whose
+// perspective projection from o covers that slope point.  Per source the workgroup builds, in LDS:
+//   * an R x R grid over slope space in CSR form (counting pass, block scan, fill pass) holding,
+//     per cell, the triangles whose projection (conservatively rasterised) overlaps the cell AND
+//     that are not entirely deeper than the deepest live face seen through that cell -- nothing
+//     deeper can be in front of any ray that will ever look the cell up;
+//   * a table of projected bounding boxes, quantised outwards to 1/256 of the grid extent.
+// A ray then walks only its own cell's list, rejects a candidate from the LDS bounding box (two
+// byte compares, no global access) and runs the exact triangle test on the few that remain.  The
+// kernel is bound by the vector-memory pipeline (divergent 48-byte record gathers), so everything
+// in front of the record load lives in LDS.  The accepted samples are identical to the BVH
+// path's: lists and boxes are supersets of what the exact test could report.  Sources for which
+// the scene is not strictly in front of the wall point, or whose grid overflows its LDS budget,
+// fall back to the stackless BVH traversal.
+struct GridView {
+    float gx0, gy0, inv_cw, inv_ch;   // cell = floor((m - g0) * inv_c)
+    float z0, inv_qz;                 // quantised depth = floor((z - z0) * inv_qz), zmax levels over the scene
+    int ib, zmax;                     // entry = index (ib bits) | x0:3 x1:3 y0:3 y1:3 | depth (32-12-ib bits)
+    int R;
+};
+
+__device__ __forceinline__ int cell_coord(float m, float g0, float inv_c, int R) {
+    int c = (int)floorf((m - g0) * inv_c);
+    return min(max(c, 0), R - 1);
+}
+
+struct Proj2 { float ax, ay, bx, by, cx, cy; };
+
+__device__ __forceinline__ Proj2 project_tri(V3 o, V3 p0, V3 p1, V3 p2) {
+    // conservative uses only: approximate reciprocals are covered by the margins below
+    const float iz0 = __builtin_amdgcn_rcpf(p0.z - o.z), iz1 = __builtin_amdgcn_rcpf(p1.z - o.z),
+                iz2 = __builtin_amdgcn_rcpf(p2.z - o.z);
+    Proj2 q;
+    q.ax = (p0.x - o.x) * iz0; q.ay = (p0.y - o.y) * iz0;
+    q.bx = (p1.x - o.x) * iz1; q.by = (p1.y - o.y) * iz1;
+    q.cx = (p2.x - o.x) * iz2; q.cy = (p2.y - o.y) * iz2;
+    return q;
+}
+
+// Cell-list entry (32 bit, LDS), most significant first:
+//   [31:25] smallest depth of the triangle, quantised downwards to 128 levels over the scene's depth range
+//   [24:19] y mask, [18:13] x mask: which sixths of THIS cell the triangle's projected bounding box touches
+//   [12:0]  index of the triangle (Morton order); the grid path is limited to F <= 8191
+// A ray carries  rlim = (its own hit depth level << 25) | 0x1FFFFFF  and  rmask = its sub-cell bit in
+// both masks; a candidate survives iff  w <= rlim  (not entirely behind the hit),  (w & rmask) == rmask
+// (the slope point is inside the box) and it is not the ray's own face: three compares on one LDS word.
+struct BBoxF { float x0, x1, y0, y1; };
+constexpr int kSub = 6;          // sub-cell levels per axis
+constexpr int kIdxBits = 13;      // single-workgroup grid: 7 depth bits
+constexpr int kIdxBitsTiled = 14; // tiled grid: subsets up to 16383 triangles, 6 depth bits
+
+__device__ __forceinline__ uint32_t make_entry(const GridView& g, const BBoxF& bb, int xx, int yy, uint32_t zq, int k) {
+    // the box is widened by 0.02 sub-cells: > 50x the fp32 error of the two projections (rcp, 1 ulp)
+    const float fx0 = ((bb.x0 - g.gx0) * g.inv_cw - (float)xx) * (float)kSub - 0.02f;
+    const float fx1 = ((bb.x1 - g.gx0) * g.inv_cw - (float)xx) * (float)kSub + 0.02f;
+    const float fy0 = ((bb.y0 - g.gy0) * g.inv_ch - (float)yy) * (float)kSub - 0.02f;
+    const float fy1 = ((bb.y1 - g.gy0) * g.inv_ch - (float)yy) * (float)kSub + 0.02f;
+    const int a0 = min(max((int)floorf(fx0), 0), kSub - 1), a1 = min(max((int)floorf(fx1), 0), kSub - 1);
+    const int b0 = min(max((int)floorf(fy0), 0), kSub - 1), b1 = min(max((int)floorf(fy1), 0), kSub - 1);
+    const uint32_t xm = (2u << a1) - (1u << a0), ym = (2u << b1) - (1u << b0);
+    return (zq << (g.ib + 2 * kSub)) | (ym << (g.ib + kSub)) | (xm << g.ib) | (uint32_t)k;
+}
+
+// conservative rasterisation of a projected triangle: fn(xx, yy) for every overlapped cell
+template <class Fn>
+__device__ __forceinline__ void raster_tri(const GridView& g, const Proj2& q, Fn fn) {
+    const float cw = __builtin_amdgcn_rcpf(g.inv_cw), ch = __builtin_amdgcn_rcpf(g.inv_ch);
+    const float mgx = 1e-3f * cw, mgy = 1e-3f * ch;          // >> fp32 rounding of the projection
+    const int cx0 = cell_coord(fminf(fminf(q.ax, q.bx), q.cx) - mgx, g.gx0, g.inv_cw, g.R);
+    const int cx1 = cell_coord(fmaxf(fmaxf(q.ax, q.bx), q.cx) + mgx, g.gx0, g.inv_cw, g.R);
+    const int cy0 = cell_coord(fminf(fminf(q.ay, q.by), q.cy) - mgy, g.gy0, g.inv_ch, g.R);
+    const int cy1 = cell_coord(fmaxf(fmaxf(q.ay, q.by), q.cy) + mgy, g.gy0, g.inv_ch, g.R);
+    // edge functions, oriented so that the inside is >= 0
+    const float area = (q.bx - q.ax) * (q.cy - q.ay) - (q.by - q.ay) * (q.cx - q.ax);
+    const float sgn = area < 0.0f ? -1.0f : 1.0f;
+    const bool thin = fabsf(area) < 1e-4f * cw * ch;         // edge-on: bbox cells only
+    const float A0 = -(q.by - q.ay) * sgn, B0 = (q.bx - q.ax) * sgn, C0 = -(A0 * q.ax + B0 * q.ay);
+    const float A1 = -(q.cy - q.by) * sgn, B1 = (q.cx - q.bx) * sgn, C1 = -(A1 * q.bx + B1 * q.by);
+    const float A2 = -(q.ay - q.cy) * sgn, B2 = (q.ax - q.cx) * sgn, C2 = -(A2 * q.cx + B2 * q.cy);
+    const float t0 = 2e-3f * (fabsf(A0) * cw + fabsf(B0) * ch);
+    const float t1 = 2e-3f * (fabsf(A1) * cw + fabsf(B1) * ch);
+    const float t2 = 2e-3f * (fabsf(A2) * cw + fabsf(B2) * ch);
+    for (int yy = cy0; yy <= cy1; ++yy) {
+        const float y0 = g.gy0 + (float)yy * ch, y1 = y0 + ch;
+        for (int xx = cx0; xx <= cx1; ++xx) {
+            const float x0 = g.gx0 + (float)xx * cw, x1 = x0 + cw;
+            bool in = true;
+            if (!thin) {
+                in = (A0 * (A0 > 0 ? x1 : x0) + B0 * (B0 > 0 ? y1 : y0) + C0 >= -t0) &&
+                     (A1 * (A1 > 0 ? x1 : x0) + B1 * (B1 > 0 ? y1 : y0) + C1 >= -t1) &&
+                     (A2 * (A2 > 0 ? x1 : x0) + B2 * (B2 > 0 ? y1 : y0) + C2 >= -t2);
+            }
+            if (in) fn(xx, yy);
+        }
+    }
+}
+
+// Slope-space frame of a source: bounding rectangle of the projection of the BVH's (padded) root box.
+// Shared by the grid kernel and the tile-binning kernel, which must agree bit for bit.
+struct SourceFrame { bool ok; float gx0, gy0, wx, wy, zr0, zr1; };
+__device__ __forceinline__ SourceFrame source_frame(const float4* __restrict__ nodes, V3 o) {
+    SourceFrame fr;
+    const float4 ra = nodes[0], rb = nodes[1];
+    fr.zr0 = ra.z - o.z;
+    fr.zr1 = rb.y - o.z;
+    const float ext = fmaxf(fmaxf(ra.w - ra.x, rb.x - ra.y), rb.y - ra.z);
+    fr.ok = fr.zr0 > 0.02f * ext && fr.zr0 > 0.0f;
+    const float i0 = 1.0f / fmaxf(fr.zr0, 1e-30f), i1 = 1.0f / fmaxf(fr.zr1, 1e-30f);
+    const float xl = ra.x - o.x, xh = ra.w - o.x, yl = ra.y - o.y, yh = rb.x - o.y;
+    const float gx0 = fminf(xl * i0, xl * i1), gx1 = fmaxf(xh * i0, xh * i1);
+    const float gy0 = fminf(yl * i0, yl * i1), gy1 = fmaxf(yh * i0, yh * i1);
+    fr.wx = fmaxf(gx1 - gx0, 1e-12f);
+    fr.wy = fmaxf(gy1 - gy0, 1e-12f);
+    fr.gx0 = gx0 - 1e-3f * fr.wx;
+    fr.gy0 = gy0 - 1e-3f * fr.wy;
+    return fr;
+}
+
+// Tile binning for the tiled grid: one workgroup per source appends every triangle to the subset of each
+// slope-space tile its projected bounding box meets (with the rasteriser's margin).  O(F) per source -- the
+// tiles' workgroups then read their subset instead of scanning the whole mesh each.
+__global__ __launch_bounds__(512) void k_tile_bin(ForwardArgs a, int R) {
+    const int l = blockIdx.x;
+    const V3 o = ld3(a.src.origin + 3 * (size_t)l);
+    const SourceFrame fr = source_frame(a.sc.nodes, o);
+    if (!fr.ok) return;                                   // tile 0 handles such a source alone
+    const int ntx = a.tiles_x, nty = a.tiles_y;
+    const float tw = fr.wx * 1.002f / (float)ntx, th = fr.wy * 1.002f / (float)nty;
+    const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+    const float mx = 2e-3f * tw / (float)R, my = 2e-3f * th / (float)R;
+    // slot allocation with LDS counters (one workgroup owns the whole source): global atomics on the few
+    // per-tile counters were the bottleneck (2.5 ms for 1024 sources x 20 k faces)
+    __shared__ int s_cnt[1024];
+    const int ntile = ntx * nty;
+    for (int i = threadIdx.x; i < ntile; i += blockDim.x) s_cnt[i] = 0;
+    __syncthreads();
+    uint32_t* lists = a.tile_list + (size_t)l * ntile * a.tile_cap;
+    for (int j = threadIdx.x; j < a.sc.F; j += blockDim.x) {
+        const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
+        const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
+        const float bx0 = fminf(fminf(q.ax, q.bx), q.cx) - mx, bx1 = fmaxf(fmaxf(q.ax, q.bx), q.cx) + mx;
+        const float by0 = fminf(fminf(q.ay, q.by), q.cy) - my, by1 = fmaxf(fmaxf(q.ay, q.by), q.cy) + my;
+        // one extra tile on each side covers the rounding of the tile origins (gx0 + t * tw)
+        const int t0 = max((int)floorf((bx0 - fr.gx0) * inv_tw - 1e-3f), 0), t1 = min((int)floorf((bx1 - fr.gx0) * inv_tw + 1e-3f), ntx - 1);
+        const int u0 = max((int)floorf((by0 - fr.gy0) * inv_th - 1e-3f), 0), u1 = min((int)floorf((by1 - fr.gy0) * inv_th + 1e-3f), nty - 1);
+        for (int u = u0; u <= u1; ++u)
+            for (int t = t0; t <= t1; ++t) {
+                const int ti = u * ntx + t;
+                const int pos = atomicAdd(&s_cnt[ti], 1);
+                if (pos < a.tile_cap) lists[(size_t)ti * a.tile_cap + pos] = (uint32_t)j;
+            }
+    }
+    __syncthreads();
+    int* cnt = a.tile_count + (size_t)l * ntile;
+    for (int i = threadIdx.x; i < ntile; i += blockDim.x) cnt[i] = s_cnt[i];
+}
+
+// two 512-thread workgroups per CU = 4 waves per SIMD: keep the kernel within 128 VGPRs
+// NCM (row N, non-confocal pairs): 0 = confocal; 1 = visibility-only pass from the SENSOR of each pair
+// (bits -> a.vis2, no histogram); 2 = pass from the LASER that evaluates both legs' geometry, ANDs the
+// sensor-leg bits and traces only the laser leg.  One perspective grid serves one origin, so a pair costs
+// two grid passes (about 2x the confocal forward) instead of two BVH traversals per sample (9x).
+//
+// TILED (meshes whose cell lists do not fit one workgroup's LDS, F > ~7.6 k): slope space is cut into
+// tiles_x * tiles_y tiles and one workgroup handles one (source, tile): it selects the triangles whose
+// projected bounding box meets its tile (ids -> a.tile_list, at most 8191: the 13-bit entry index is then
+// an index into that list), builds the grid over the tile only, and traces exactly the samples whose
+// slope point falls into the tile -- every sample is owned by one tile, decided from the source's global
+// frame so that all workgroups of a source agree.  Rows and visibility words are combined with atomics
+// (the launcher zeroes them).  A tile whose subset overflows iterates over all faces and uses the BVH
+// query for its own samples; a source whose scene is not strictly in front is handled by tile 0 alone.
+// Tiles whose cell lists overflow the normal LDS share (two workgroups per CU) flag themselves and leave
+// before writing anything; a second launch (`pass` = 1) with one workgroup per CU and ~150 KB of LDS redoes
+// exactly those tiles (grazing views pile thousands of sliver triangles into a few tiles).
+template <int FEAT, int NCM = 0, bool TILED = false>
+__global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows_in_lds, int R, int cap, int pass = 0) {
+    // dynamic LDS: [ctl: ticket, bad, total, n_live (16 B)][row nbins f64][cells R*R+1 u32]
+    //   [union { build: depth bound per 2x2 cells R2*R2 u32, block masks nblk u64 ;
+    //            trace: 8 waves x (128 queued pairs + 2 mask words) }][entries cap u32]
+    // (the bucketed live-face list lives in global scratch: it is read once per 64-face block)
+    extern __shared__ double s_lds[];
+    constexpr int IB = TILED ? kIdxBitsTiled : kIdxBits;
+    if (TILED && pass == 1 && a.tile_count[gridDim.x + blockIdx.x] == 0) return;     // only the flagged tiles
+    int* s_ctl = reinterpret_cast<int*>(s_lds);      // 8 ints: ticket, bad, total entries, n_live, tile subset size
+    double* s_row = s_lds + 4;
+    const int nbins = a.sp.nbins;
+    const int ncell = R * R;
+    const int R2 = (R + 1) >> 1;
+    const int F = a.sc.F;
+    const int ntiles = TILED ? a.tiles_x * a.tiles_y : 1;
+    const int tile = TILED ? (int)(blockIdx.x % (unsigned)ntiles) : 0;
+    const int tile_x = TILED ? tile % a.tiles_x : 0, tile_y = TILED ? tile / a.tiles_x : 0;
+    const int mask_blocks = TILED ? max((a.tile_cap + 63) >> 6, (F + 63) >> 6) : (F + 63) >> 6;   // LDS sizing only
+    uint32_t* s_cell = reinterpret_cast<uint32_t*>(s_row + (rows_in_lds ? nbins : 0));
+    uint32_t* s_union = s_cell + ((ncell + 2) & ~1);
+    uint32_t* s_zc = s_union;                                                   // build phase
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(s_zc + ((R2 * R2 + 1) & ~1));
+    uint32_t* s_queue = s_union;                                                // trace phase
+    const int union_words = max(((R2 * R2 + 1) & ~1) + 2 * mask_blocks, 8 * 130);
+    uint32_t* s_ent = s_union + ((union_words + 1) & ~1);
+    uint16_t* g_live = a.live + (size_t)blockIdx.x * (TILED ? a.tile_cap : F);
+    uint32_t* tl = TILED ? a.tile_list + (size_t)blockIdx.x * a.tile_cap : nullptr;
+    __shared__ uint32_t s_scan[512];
+
+    const int l = TILED ? (int)(blockIdx.x / (unsigned)ntiles) : (int)blockIdx.x;
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = NT >> 6;
+    const V3 o = ld3((NCM == 1 ? a.src.sensor : a.src.origin) + 3 * (size_t)l);
+    const V3 on = ld3((NCM == 1 ? a.src.sensor_normal : a.src.normal) + 3 * (size_t)l);
+    const V3 ob = NCM == 2 ? ld3(a.src.sensor + 3 * (size_t)l) : o;
+    const V3 onb = NCM == 2 ? ld3(a.src.sensor_normal + 3 * (size_t)l) : on;
+    uint32_t* const visout = NCM == 1 ? a.vis2 : a.vis;
+#ifdef NLOS_FWD_STAMPS
+    // diagnostic build only: per-phase cycles summed over workgroups -> a.dbg[0..5]
+    long long t_prev = clock64();
+    int t_slot = 0;
+#define FWD_STAMP() do { __syncthreads(); if (tid == 0 && a.dbg) { long long t_now = clock64(); atomicAdd((unsigned long long*)&a.dbg[t_slot], (unsigned long long)(t_now - t_prev)); ++t_slot; t_prev = t_now; } } while (0)
+#else
+#define FWD_STAMP() do { } while (0)
+#endif
+
+    // ---- grid frame from the (padded) root box of the BVH: O(1) per source ------------------
+    const SourceFrame fr = source_frame(a.sc.nodes, o);
+    const float zr0 = fr.zr0, zr1 = fr.zr1;
+    const bool frame_ok = fr.ok;
+    GridView g;
+    g.R = R;
+    float Gx0 = 0.0f, Gy0 = 0.0f, inv_tw = 0.0f, inv_th = 0.0f;     // TILED: the source's global frame
+    {
+        const float wx = fr.wx, wy = fr.wy;
+        g.gx0 = fr.gx0;
+        g.gy0 = fr.gy0;
+        g.inv_cw = (float)R / (wx * 1.002f);
+        g.inv_ch = (float)R / (wy * 1.002f);
+        if (TILED) {
+            // the source's frame [G0, G0 + W) is cut into tiles; ownership of a slope point is decided
+            // with (G0, inv_tw) only, which every workgroup of the source computes identically
+            Gx0 = g.gx0; Gy0 = g.gy0;
+            const float tw = wx * 1.002f / (float)a.tiles_x, th = wy * 1.002f / (float)a.tiles_y;
+            inv_tw = 1.0f / tw; inv_th = 1.0f / th;
+            g.gx0 = Gx0 + (float)tile_x * tw;
+            g.gy0 = Gy0 + (float)tile_y * th;
+            g.inv_cw = (float)R / tw;
+            g.inv_ch = (float)R / th;
+        }
+        g.ib = IB;
+        g.zmax = (1 << (32 - 2 * kSub - IB)) - 1;
+        g.z0 = zr0;
+        g.inv_qz = (float)g.zmax / fmaxf(zr1 - zr0, 1e-12f);
+    }
+
+    if (rows_in_lds)
+        for (int i = tid; i < nbins; i += NT) s_row[i] = 0.0;
+    for (int i = tid; i <= ncell; i += NT) s_cell[i] = 0u;
+    for (int i = tid; i < R2 * R2; i += NT) s_zc[i] = 0u;
+    if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = frame_ok ? 0 : 1; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[4] = 0; }
+    __syncthreads();
+
+    // Fl faces are iterated by this workgroup; `ident`: local index == sorted face index
+    int Fl = F;
+    bool ident = true;
+    if (TILED) {
+        if (!frame_ok) {
+            if (tile != 0) return;                     // tile 0 handles such a source alone (BVH queries)
+        } else {
+            // ---- tile subset, binned by k_tile_bin
+            const int nsel = a.tile_count[blockIdx.x];
+#ifdef NLOS_FWD_STAMPS
+            if (tid == 0 && a.dbg) {
+                if (nsel > a.tile_cap) atomicAdd((unsigned long long*)&a.dbg[22], 1ull);
+                atomicMax((unsigned long long*)&a.dbg[23], (unsigned long long)nsel);
+            }
+#endif
+            if (nsel > a.tile_cap || nsel > (1 << IB) - 1) {
+                if (tid == 0) s_ctl[1] = 1;            // subset overflow: all faces, BVH query, own samples only
+            } else {
+                Fl = nsel;
+                ident = false;
+            }
+            __syncthreads();
+        }
+    }
+    const int nblocks = (Fl + 63) >> 6;
+    auto gid = [&](int j) -> int { return (TILED && !ident) ? (int)tl[j] : j; };
+    const bool compact = !(TILED && ident);            // ident tiles may exceed the u16 live list: no compaction
+
+    // ---- which faces can contribute at all?  (order-preserving compaction, per 64-face block) ----
+    // With face normals and the clamped form factor, -dot(n,dir) has the sign of dist(o, plane(f))
+    // for every sample of f: if the wall point is clearly behind the face (and the face in front
+    // of the wall), every contribution is exactly 0 -- nothing to sample, nothing to trace.
+    // Live faces also record, per 2x2 block of cells they project to, the largest depth at which
+    // a ray of this source can end.
+    auto face_dark = [&](const Face& f) -> bool {
+        bool dark = f.degenerate;
+        if (!dark && !(FEAT & FEAT_VN) && a.sp.clamp) {
+            const float dist = dot(f.fn, o - f.p0);
+            const float sc = fabsf(o.x - f.p0.x) + fabsf(o.y - f.p0.y) + fabsf(o.z - f.p0.z);
+            const bool behind = dist < -1e-4f * sc;
+            const bool infront = dot(on, f.p0 - o) > 1e-4f * sc && dot(on, f.p1 - o) > 1e-4f * sc &&
+                                 dot(on, f.p2 - o) > 1e-4f * sc;
+            dark = behind && infront;
+        }
+        return dark;
+    };
+    for (int b = wave; b < nblocks; b += nwaves) {
+        const int j = (b << 6) + lane;
+        bool live = false;
+        if (j < Fl) {
+            const int jg = gid(j);
+            const Face f = load_face(a.sc.facerec, jg);
+            const bool dark = face_dark(f);
+            live = !dark;
+            if (!TILED && dark && visout) {
+                uint32_t* visp = visout + ((size_t)l * a.vis_words) * F + j;
+                for (int wi = 0; wi < a.vis_words; ++wi) visp[(size_t)wi * F] = 0u;
+            }
+            if (live && frame_ok && !(TILED && ident)) {
+                const float zfar = fmaxf(fmaxf(f.p0.z, f.p1.z), f.p2.z) - o.z;
+                const uint32_t zb = __float_as_uint(fmaxf(zfar, 0.0f) * 1.0001f + 1e-30f);
+                const Proj2 q = project_tri(o, f.p0, f.p1, f.p2);
+                raster_tri(g, q, [&](int xx, int yy) { atomicMax(&s_zc[(yy >> 1) * R2 + (xx >> 1)], zb); });
+            }
+        }
+        const unsigned long long m = __ballot(live);
+        if (lane == 0) s_mask[b] = m;
+    }
+    __syncthreads();
+    FWD_STAMP();   // 0: setup + live-face masks + depth bounds
+
+    if (frame_ok && !(TILED && ident)) {
+        // ---- counting pass ---------------------------------------------------------------------------
+        for (int jl = tid; jl < Fl; jl += NT) {
+            const int j = gid(jl);
+            const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
+            const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
+            const uint32_t zn = __float_as_uint(fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f));
+            raster_tri(g, q, [&](int xx, int yy) {
+                if (zn <= s_zc[(yy >> 1) * R2 + (xx >> 1)]) atomicAdd(&s_cell[yy * R + xx], 1u);
+            });
+        }
+    }
+    __syncthreads();
+    FWD_STAMP();   // 1: counting pass
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < nblocks; ++b) run += (uint32_t)__popcll(s_mask[b]);
+        s_ctl[3] = (int)run;
+    }
+    if (frame_ok) {
+        // ---- exclusive scan of the cell counts (each thread owns a contiguous slice) -------------
+        const int per = (ncell + NT - 1) / NT;
+        const int c0 = min(tid * per, ncell), c1 = min(c0 + per, ncell);
+        uint32_t sum = 0;
+        for (int c = c0; c < c1; ++c) sum += s_cell[c];
+        s_scan[tid] = sum;
+        __syncthreads();
+        for (int off = 1; off < NT; off <<= 1) {
+            uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        uint32_t run = s_scan[tid] - sum;
+        for (int c = c0; c < c1; ++c) { uint32_t n = s_cell[c]; s_cell[c] = run; run += n; }
+        if (tid == NT - 1) { s_ctl[2] = (int)s_scan[tid]; if ((int)s_scan[tid] > cap) s_ctl[1] = 1; }
+    }
+    __syncthreads();
+    if (TILED && pass == 0 && frame_ok && !ident && s_ctl[1] != 0) {
+        if (tid == 0) a.tile_count[gridDim.x + blockIdx.x] = 1;      // cell lists overflow: redo with the big-LDS launch
+        return;
+    }
+    FWD_STAMP();   // 2: scans
+    // ---- fill pass: s_cell[c] is the write cursor, afterwards the END of cell c ------------------
+    if (frame_ok && s_ctl[1] == 0) {
+        for (int jl = tid; jl < Fl; jl += NT) {
+            const int j = gid(jl);
+            const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
+            const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
+            const float zmin_rel = fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f);
+            const uint32_t zn = __float_as_uint(zmin_rel);
+            const uint32_t zq = (uint32_t)min(max((int)floorf((zmin_rel - g.z0) * g.inv_qz) - 1, 0), g.zmax);
+            BBoxF bb;
+            bb.x0 = fminf(fminf(q.ax, q.bx), q.cx); bb.x1 = fmaxf(fmaxf(q.ax, q.bx), q.cx);
+            bb.y0 = fminf(fminf(q.ay, q.by), q.cy); bb.y1 = fmaxf(fmaxf(q.ay, q.by), q.cy);
+            raster_tri(g, q, [&](int xx, int yy) {
+                if (zn <= s_zc[(yy >> 1) * R2 + (xx >> 1)]) {
+                    uint32_t pos = atomicAdd(&s_cell[yy * R + xx], 1u);
+                    s_ent[pos] = make_entry(g, bb, xx, yy, zq, jl);
+                }
+            });
+        }
+    }
+    __syncthreads();
+    FWD_STAMP();   // 3: fill pass
+    // ---- live list, bucketed by the length of the list of the face's centroid cell ----------------
+    // Cell lists have a heavy tail (mean 16, max > 60 entries) and the filter walk below is a
+    // lockstep loop: a wave is as slow as its longest list.  Handing out the live faces in
+    // buckets of similar list length (longest first) makes the 64 lists of a wave comparable.
+    const bool use_grid = s_ctl[1] == 0;
+#ifdef NLOS_FWD_STAMPS
+    if (TILED && tid == 0 && a.dbg && !use_grid && !ident) atomicAdd((unsigned long long*)&a.dbg[20], 1ull);   // entry overflow
+    if (TILED && tid == 0 && a.dbg) atomicMax((unsigned long long*)&a.dbg[21], (unsigned long long)s_ctl[2]);
+#endif
+    constexpr int NB = 16;                                   // buckets of 4 entries
+    auto face_bucket = [&](int j) -> int {
+        if (!use_grid) return 0;
+        // longest list among the cells under the face's projected bounding box
+        const int jg = gid(j);
+        const float4 q0 = a.sc.facerec[4 * jg], q1 = a.sc.facerec[4 * jg + 1], q2 = a.sc.facerec[4 * jg + 2];
+        const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
+        const int cx0 = cell_coord(fminf(fminf(q.ax, q.bx), q.cx), g.gx0, g.inv_cw, R);
+        const int cx1 = cell_coord(fmaxf(fmaxf(q.ax, q.bx), q.cx), g.gx0, g.inv_cw, R);
+        const int cy0 = cell_coord(fminf(fminf(q.ay, q.by), q.cy), g.gy0, g.inv_ch, R);
+        const int cy1 = cell_coord(fmaxf(fmaxf(q.ay, q.by), q.cy), g.gy0, g.inv_ch, R);
+        uint32_t n = 0;
+        for (int yy = cy0; yy <= cy1; ++yy)
+            for (int xx = cx0; xx <= cx1; ++xx) {
+                const int c = yy * R + xx;
+                n = max(n, s_cell[c] - (c > 0 ? s_cell[c - 1] : 0u));
+            }
+        return (NB - 1) - (int)min(n >> 2, (uint32_t)(NB - 1));   // bucket 0 = longest lists
+    };
+    if (tid < 2 * NB) s_scan[tid] = 0u;
+    __syncthreads();
+    for (int b = wave; compact && b < nblocks; b += nwaves) {
+        if ((s_mask[b] >> lane) & 1ull) atomicAdd(&s_scan[face_bucket((b << 6) + lane)], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int q = 0; q < NB; ++q) { s_scan[NB + q] = run; run += s_scan[q]; }
+    }
+    __syncthreads();
+    for (int b = wave; compact && b < nblocks; b += nwaves) {
+        if ((s_mask[b] >> lane) & 1ull) {
+            const int j = (b << 6) + lane;
+            g_live[atomicAdd(&s_scan[NB + face_bucket(j)], 1u)] = (uint16_t)j;
+        }
+    }
+    __syncthreads();
+    FWD_STAMP();   // 4: bucketed live list
+    const int n_live = compact ? s_ctl[3] : Fl;
+    const int live_blocks = (n_live + 63) >> 6;
+
+    // ---- trace + histogram: dense lanes over the live faces ----------------------------------------
+    // Per sample the 64 rays of a wave are handled in two wave-synchronous stages:
+    //  (1) filter: every lane walks its own cell list in lockstep with LDS-only work (entry index +
+    //      quantised projected box) and appends the survivors, as (owner lane, triangle) pairs, to a
+    //      wave-private LDS queue (ballot + prefix rank);
+    //  (2) exact test: whenever 64 pairs are queued (and at the end) each lane takes ONE pair, pulls
+    //      the owner's ray through ds_bpermute, gathers the 48-byte record and runs the triangle
+    //      test; hits are OR-ed into the wave's occlusion mask.
+    // The kernel is VALU-issue bound and cell lists have a heavy tail (mean 17, wave-max 36
+    // entries; 5.7 exact tests per ray at 22 % lane occupancy when done in place), so the expensive
+    // stage must run on dense lanes and must not wait for the longest list.
+    const uint64_t lg = (uint64_t)(a.src.source_offset + l);
+    const int spt = a.sp.spt;
+    const float lb = a.sp.lb, ub = a.sp.ub, res = a.sp.res;
+    double* grow = a.rows ? a.rows + (size_t)l * nbins : nullptr;
+#ifdef NLOS_FWD_STAMPS
+    unsigned long long c_rays = 0, c_pairs = 0, c_iters = 0, c_mt = 0, c_mtw = 0;   // diagnostic build only
+    long long tg = 0, ts = 0, tx = 0, th = 0, tmark = 0;
+#define TMARK() (tmark = clock64())
+#define TACC(v) do { long long now_ = clock64(); v += now_ - tmark; tmark = now_; } while (0)
+#else
+#define TMARK() do { } while (0)
+#define TACC(v) do { } while (0)
+#endif
+    uint32_t* wq = s_queue + wave * 128;                 // this wave's pair queue (aliases the build-phase tables)
+    uint32_t* wocc = s_queue + nwaves * 128 + wave * 2;  // this wave's 64-bit occlusion mask
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    for (;;) {
+        const int b = wave_ticket(&s_ctl[0]);
+        if (b >= live_blocks) break;
+        const int li = (b << 6) + lane;
+        bool has_face = li < n_live;
+        const int j = has_face ? (compact ? (int)g_live[li] : li) : 0;     // index within this workgroup's face set
+        const int jg = gid(j);                                              // sorted-face index
+        const Face f = load_face(a.sc.facerec, jg);
+        if (!compact && has_face) has_face = !face_dark(f);                 // (the block masks are gone: the queue reuses their LDS)
+        if (TILED && !compact && has_face && frame_ok) {
+            // overflowed subset: every face is visited, most of them lie outside this tile
+            const Proj2 q = project_tri(o, f.p0, f.p1, f.p2);
+            const float cwm = __builtin_amdgcn_rcpf(g.inv_cw) * (1.0f + 4e-3f), chm = __builtin_amdgcn_rcpf(g.inv_ch) * (1.0f + 4e-3f);
+            has_face = fmaxf(fmaxf(q.ax, q.bx), q.cx) >= g.gx0 - 4e-3f * cwm && fminf(fminf(q.ax, q.bx), q.cx) <= g.gx0 + (float)R * cwm &&
+                       fmaxf(fmaxf(q.ay, q.by), q.cy) >= g.gy0 - 4e-3f * chm && fminf(fminf(q.ay, q.by), q.cy) <= g.gy0 + (float)R * chm;
+        }
+        uint32_t* visp = (visout && has_face) ? visout + ((size_t)l * a.vis_words) * F + jg : nullptr;
+        const uint32_t* visb = (NCM == 2 && has_face) ? a.vis2 + ((size_t)l * a.vis_words) * F + jg : nullptr;
+        const Tri tr = load_tri(a.sc.tris, jg);
+        const uint64_t kbase = (lg * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
+        uint32_t word = 0, word_b = 0;
+        double inten = 0.0;
+        for (int s = 0; s < spt; ++s) {
+            TMARK();
+            V3 dir = mk(0.0f, 0.0f, 1.0f);
+            float t_self = 0.0f, val = 0.0f;
+            int bin = -1;
+            bool ok = has_face;
+            if (NCM == 2 && (s & 31) == 0 && has_face) word_b = visb[(size_t)(s >> 5) * F];
+            if (NCM == 0) {
+                Geo gg;
+                if (ok)
+                    ok = sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, lb, ub, a.sc.vertex_normal,
+                                          a.sc.albedo, gg, t_self);
+                if (ok) {
+                    float ff = -dot(gg.n, gg.dir) * dot(on, gg.dir) / gg.h / gg.h;
+                    if (a.sp.clamp) {
+                        ff = emax0(ff);
+                        ok = ff > 0.0f;
+                    }
+                    val = f.area * gg.alb * ff * ff;
+                    if (FEAT & FEAT_GGX) val = val * ggx_eval(a.sp.ggx_alpha, dot(gg.n, -gg.dir));
+                    bin = (int)floorf((2.0f * gg.h - lb) / res);
+                    dir = gg.dir;
+                }
+            } else if (NCM == 1) {
+                // sensor leg only: is the stratified point the closest hit seen from the sensor?
+                if (ok) {
+                    float S, T;
+                    sample_st(a.sp.seed, kbase + (uint64_t)s, S, T);
+                    const float sq = sqrtf(T);
+                    const V3 p = bary(1 - sq, f.p0, (1 - S) * sq, f.p1, S * sq, f.p2);
+                    const V3 d = p - o;
+                    dir = d * (1.0f / sqrtf(dot(d, d)));
+                    float hu, hv;
+                    ok = tri_test(tr, o, dir, t_self, hu, hv);
+                    // a leg whose form factor is exactly zero is rejected by the laser pass anyway: skip its ray
+                    if (ok && !(FEAT & FEAT_VN)) ok = (-dot(f.fn, dir) * dot(on, dir)) > 0.0f;
+                }
+            } else {
+                GeoNC gc;
+                float t_b;
+                if (ok)
+                    ok = sample_geo_nc<FEAT>(f, tr, o, ob, a.sp.seed, kbase + (uint64_t)s, lb, ub, a.sc.vertex_normal,
+                                             a.sc.albedo, gc, t_self, t_b);
+                if (ok) {
+                    const float ffa = emax0(-dot(gc.n, gc.dirA) * dot(on, gc.dirA) / gc.d1 / gc.d1);
+                    const float ffb = emax0(-dot(gc.n, gc.dirB) * dot(onb, gc.dirB) / gc.d2 / gc.d2);
+                    ok = ffa > 0.0f && ffb > 0.0f && ((word_b >> (s & 31)) & 1u);
+                    val = f.area * gc.alb * ffa * ffb;
+                    bin = (int)floorf(((gc.d1 + gc.d2) - lb) / res);
+                    dir = gc.dirA;
+                }
+            }
+            if (TILED && ok && frame_ok) {
+                // the tile that owns this sample: from the source's global frame, identical in every workgroup
+                const float izo = __builtin_amdgcn_rcpf(dir.z);
+                const int ti = min(max((int)floorf((dir.x * izo - Gx0) * inv_tw), 0), a.tiles_x - 1);
+                const int tj = min(max((int)floorf((dir.y * izo - Gy0) * inv_th), 0), a.tiles_y - 1);
+                ok = dir.z > 0.0f ? (ti == tile_x && tj == tile_y) : tile == 0;
+            }
+            if (!ok) dir = mk(0.0f, 0.0f, 1.0f);
+            const bool grid_ray = ok && use_grid && dir.z > 0.0f;
+            if (ok && !grid_ray)
+                ok = !occluded(a.sc.nodes, a.sc.n_nodes, a.sc.tris, a.sc.face_id, o, dir, t_self, jg, f.fid);
+
+            // ---- stage 1 + 2 (wave-synchronous; every lane takes part) ----
+            uint32_t e = 0, e1 = 0, rmask = 0, rlim = 0;
+            if (grid_ray) {
+                const float iz = __builtin_amdgcn_rcpf(dir.z);   // lookups only: 1-ulp rcp is fine
+                const float ux = (dir.x * iz - g.gx0) * g.inv_cw, uy = (dir.y * iz - g.gy0) * g.inv_ch;
+                const int cxx = min(max((int)floorf(ux), 0), R - 1), cyy = min(max((int)floorf(uy), 0), R - 1);
+                const int sx = min(max((int)floorf((ux - (float)cxx) * (float)kSub), 0), kSub - 1);
+                const int sy = min(max((int)floorf((uy - (float)cyy) * (float)kSub), 0), kSub - 1);
+                rmask = (1u << (IB + sx)) | (1u << (IB + kSub + sy));
+                // depth level of the own-face hit, rounded up: anything quantised deeper cannot occlude
+                const float zs = t_self * dir.z;
+                const uint32_t rq = (uint32_t)min(max((int)floorf((zs * 1.00002f - g.z0) * g.inv_qz) + 1, 0), g.zmax);
+                rlim = (rq << (IB + 2 * kSub)) | ((1u << (IB + 2 * kSub)) - 1u);
+                const int c = cyy * R + cxx;
+                e1 = s_cell[c];
+                e = c > 0 ? s_cell[c - 1] : 0u;
+            }
+            if (lane < 2) wocc[lane] = 0u;
+            TACC(tg);
+            int qn = 0;                                        // wave-uniform
+            auto exact_round = [&](int n) {
+#ifdef NLOS_FWD_STAMPS
+                if (lane == 0) c_mtw += 1;
+#endif
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t pr = wq[lane < n ? lane : 0];
+                const int owner = (int)(pr >> 16), k = (int)(pr & 0xFFFFu);
+                const V3 od = mk(__shfl(dir.x, owner), __shfl(dir.y, owner), __shfl(dir.z, owner));
+                const float ot = __shfl(t_self, owner);
+                const int ofid = __shfl(f.fid, owner);
+                if (lane < n) {
+                    const int kg = gid(k);
+                    const Tri tk = load_tri(a.sc.tris, kg);
+                    if (tri_occludes(tk, o, od, ot, ofid, a.sc.face_id, kg))
+                        atomicOr(&wocc[owner >> 5], 1u << (owner & 31));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            };
+            // lockstep filter walk (LDS only): entry index + packed box/depth word.  (A fully
+            // flattened walk -- pairs spread evenly over the lanes with a prefix-sum owner search --
+            // halves the iterations but its dependent ds_bpermute chain makes it slower; measured.)
+#ifdef NLOS_FWD_STAMPS
+            if (grid_ray) c_rays += 1;
+#endif
+            constexpr uint32_t imask = (1u << IB) - 1u;
+            auto push = [&](bool pass, int k) {
+                const unsigned long long m = __ballot(pass);
+                if (m) {
+                    if (pass) wq[qn + __popcll(m & lt_mask)] = ((uint32_t)lane << 16) | (uint32_t)k;
+                    qn += __popcll(m);
+                    if (qn >= 64) {
+                        TACC(ts);
+                        exact_round(64);
+                        TACC(tx);
+                        qn -= 64;
+                        const uint32_t mv = wq[64 + (lane < qn ? lane : 0)];
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < qn) wq[lane] = mv;
+                    }
+                }
+            };
+            // two entries per trip (one ds_read2_b32): halves the loop overhead of the lockstep walk
+            while (__any(e < e1)) {
+                bool p0 = false, p1 = false;
+                int k0 = 0, k1 = 0;
+                if (e < e1) {
+                    const uint32_t w0 = s_ent[e], w1 = s_ent[e + 1];
+                    k0 = (int)(w0 & imask);
+                    k1 = (int)(w1 & imask);
+                    p0 = (w0 <= rlim) & ((w0 & rmask) == rmask) & (k0 != j);
+                    p1 = (e + 1 < e1) & (w1 <= rlim) & ((w1 & rmask) == rmask) & (k1 != j);
+#ifdef NLOS_FWD_STAMPS
+                    if (grid_ray) c_pairs += (e + 1 < e1) ? 2 : 1;
+#endif
+                    e += 2;
+                }
+#ifdef NLOS_FWD_STAMPS
+                if (lane == 0) c_iters += 1;
+                if (p0) c_mt += 1;
+                if (p1) c_mt += 1;
+#endif
+                push(p0, k0);
+                push(p1, k1);
+            }
+            TACC(ts);
+            if (qn > 0) exact_round(qn);
+            TACC(tx);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (grid_ray) ok = ((wocc[lane >> 5] >> (lane & 31)) & 1u) == 0u;
+            __builtin_amdgcn_wave_barrier();
+
+            if (ok) {
+                word |= 1u << (s & 31);
+                if (NCM == 1) {
+                    // visibility only
+                } else if (a.mode_intensity) {
+                    inten += (double)val / (double)spt;
+                } else if (bin >= 0 && bin < nbins) {
+                    double cc = (double)val / (double)spt;
+                    if (rows_in_lds) unsafeAtomicAdd(&s_row[bin], cc);
+                    else unsafeAtomicAdd(&grow[bin], cc);
+                }
+            }
+            if ((s & 31) == 31 || s == spt - 1) {
+                if (visp) {
+                    if (!TILED) visp[(size_t)(s >> 5) * F] = word;
+                    else if (word) atomicOr(&visp[(size_t)(s >> 5) * F], word);   // a face may straddle tiles
+                }
+                word = 0;
+            }
+            TACC(th);
+        }
+        if (a.mode_intensity && has_face && inten != 0.0) unsafeAtomicAdd(&a.intensity[f.fid], inten);
+    }
+#ifdef NLOS_FWD_STAMPS
+    if (a.dbg) {   // diagnostic build only: work counters -> a.dbg[8..12]
+        atomicAdd((unsigned long long*)&a.dbg[8], c_rays);
+        atomicAdd((unsigned long long*)&a.dbg[9], c_pairs);
+        atomicAdd((unsigned long long*)&a.dbg[10], c_iters);
+        atomicAdd((unsigned long long*)&a.dbg[11], c_mt);
+        atomicAdd((unsigned long long*)&a.dbg[12], c_mtw);
+        if (tid == 0) atomicAdd((unsigned long long*)&a.dbg[13], (unsigned long long)s_ctl[2]);
+        if (lane == 0) {
+            atomicAdd((unsigned long long*)&a.dbg[14], (unsigned long long)tg);
+            atomicAdd((unsigned long long*)&a.dbg[15], (unsigned long long)ts);
+            atomicAdd((unsigned long long*)&a.dbg[16], (unsigned long long)tx);
+            atomicAdd((unsigned long long*)&a.dbg[17], (unsigned long long)th);
+        }
+    }
+#endif
+    FWD_STAMP();   // 5: sample + trace + histogram
+    if (rows_in_lds && grow) {
+        __syncthreads();
+        if (!TILED) {
+            for (int i = tid; i < nbins; i += NT) grow[i] = s_row[i];
+        } else {
+            for (int i = tid; i < nbins; i += NT)
+                if (s_row[i] != 0.0) unsafeAtomicAdd(&grow[i], s_row[i]);     // one partial row per tile
+        }
+    }
+}
+
+// LDS budget of the grid kernel: two 512-thread workgroups per CU (160 KiB / 2, minus slack)
+constexpr size_t kGridLdsBudget = 78 * 1024;
+
+template <int FEAT, int NCM = 0>
+bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
+    if (a.force_bvh || a.tile_list || a.sc.F > 8191 || a.sc.F < 64) return false;     // 13-bit triangle index in the cell entries
+    int R = (int)lrintf(sqrtf(0.5f * (float)a.sc.F));
+    R = std::min(std::max(R, 8), 96);
+    const size_t nblk = ((size_t)a.sc.F + 63) / 64;
+    const size_t R2 = ((size_t)R + 1) / 2;
+    size_t union_words = ((R2 * R2 + 1) & ~(size_t)1) + 2 * nblk;
+    if (union_words < 8 * 130) union_words = 8 * 130;
+    const size_t fixed = 32 + (rows_in_lds ? (size_t)a.sp.nbins * sizeof(double) : 0) + (((size_t)R * R + 2) & ~(size_t)1) * 4 +
+                         ((union_words + 1) & ~(size_t)1) * 4;
+    if (fixed + 4 * 2 * (size_t)a.sc.F > kGridLdsBudget || !a.live) return false;      // want room for >= 2 entries per face
+    size_t cap = (kGridLdsBudget - fixed) / 4;
+    const size_t lds = fixed + cap * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // one slot of slack: the walk reads entries in pairs and may touch the slot after the last list
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM>), dim3(a.src.L), dim3(512), lds, stream, a, rows_in_lds, R,
+                       (int)cap - 1);
+    return true;
+}
+
+// meshes beyond one workgroup's LDS: one workgroup per (source, slope-space tile)
+template <int FEAT>
+bool forward_tiled_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
+    if (a.force_bvh || !a.tile_list || !a.tile_count || !a.live || a.tiles_x * a.tiles_y > 1024 || a.tiles_x < 1 || a.tiles_y < 1 || a.mode_intensity || a.src.sensor) return false;
+    const int R = 32;
+    const size_t R2 = (R + 1) / 2;
+    const size_t mask_blocks = std::max(((size_t)a.tile_cap + 63) / 64, ((size_t)a.sc.F + 63) / 64);
+    size_t union_words = ((R2 * R2 + 1) & ~(size_t)1) + 2 * mask_blocks;
+    if (union_words < 8 * 130) union_words = 8 * 130;
+    const size_t fixed = 32 + (rows_in_lds ? (size_t)a.sp.nbins * sizeof(double) : 0) + (((size_t)R * R + 2) & ~(size_t)1) * 4 +
+                         ((union_words + 1) & ~(size_t)1) * 4;
+    if (fixed + 4 * 4096 > kGridLdsBudget) return false;
+    const size_t cap = (kGridLdsBudget - fixed) / 4;
+    const size_t lds = fixed + cap * 4;
+    // partial rows / visibility words of the tiles are combined with atomics: start from zero
+    if (rows_in_lds && a.rows) launch_zero_f64(a.rows, (size_t)a.src.L * a.sp.nbins, stream);
+    if (a.vis) (void)hipMemsetAsync(a.vis, 0, sizeof(uint32_t) * (size_t)a.src.L * a.vis_words * a.sc.F, stream);
+    const size_t nwg = (size_t)a.src.L * a.tiles_x * a.tiles_y;
+    (void)hipMemsetAsync(a.tile_count, 0, sizeof(int) * 2 * nwg, stream);      // subset sizes + retry flags
+    hipLaunchKernelGGL(k_tile_bin, dim3(a.src.L), dim3(512), 0, stream, a, R);
+    // second launch for the tiles whose cell lists overflow: the whole CU's LDS for one workgroup
+    const size_t lds_big = 150 * 1024;
+    const size_t cap_big = (lds_big - fixed) / 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, 0, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, 0, true>), dim3((unsigned)nwg), dim3(512), lds, stream, a, rows_in_lds, R,
+                       (int)cap - 1, 0);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, 0, true>), dim3((unsigned)nwg), dim3(512), lds_big, stream, a, rows_in_lds,
+                       R, (int)cap_big - 1, 1);
+    return true;
+}
+
+template <int FEAT>
+bool grid_dispatch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
+    if (a.src.sensor) {
+        if constexpr ((FEAT & FEAT_GGX) == 0) {
+            // row N: one grid pass per end point of the pair (sensor-leg visibility bits first, then the
+            // laser pass that ANDs them and bins)
+            if (a.vis2 && !a.mode_intensity) {
+                ForwardArgs p1 = a;
+                p1.rows = nullptr;
+                return forward_grid_launch<FEAT, 1>(p1, 0, stream) && forward_grid_launch<FEAT, 2>(a, rows_in_lds, stream);
+            }
+        }
+        return false;
+    }
+    if (forward_grid_launch<FEAT>(a, rows_in_lds, stream)) return true;
+    return forward_tiled_launch<FEAT>(a, rows_in_lds, stream);
+}
+
+}  // namespace
+
+// true: launched (single-workgroup grid, tiled grid or the two passes of non-confocal pairs);
+// false: this render needs the BVH back-end
+bool launch_forward_grid(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
+    switch (feat_of(a.sc, a.sp)) {
+        case 0: return grid_dispatch<0>(a, rows_in_lds, stream);
+        case 1: return grid_dispatch<1>(a, rows_in_lds, stream);
+        case 2: return grid_dispatch<2>(a, rows_in_lds, stream);
+        case 3: return grid_dispatch<3>(a, rows_in_lds, stream);
+        case 4: return grid_dispatch<4>(a, rows_in_lds, stream);
+        case 5: return grid_dispatch<5>(a, rows_in_lds, stream);
+        case 6: return grid_dispatch<6>(a, rows_in_lds, stream);
+        default: return grid_dispatch<7>(a, rows_in_lds, stream);
+    }
+}
+
+}  // namespace nlos

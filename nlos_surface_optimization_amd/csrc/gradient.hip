@@ -1,0 +1,471 @@
+// gradient.hip -- pass 2: analytic per-vertex / scalar gradients from the visibility cache (gfx950).
+//
+//   k_gradient<FEAT, MODE, NC>  <- streamedRayTraceTriangleGradient / ...GradientAlbedo / ...GradientAlpha /
+//                                  ...VertexGradient (smoothed_transient/transient_and_gradient.cpp:843-1007,
+//                                  :571-695, ggx/transient_and_gradient.cpp:385-512, :697-840) + reduction
+//                                  (:561-565); jitter taps (jitter/transient_and_gradient.cpp:944-969)
+//   k_gradient_fm<FEAT>         the vertex gradient for meshes whose 3V-double accumulator does not fit LDS
+// No ray is traced here: pass 1 left one bit per accepted sample.
+#include "render_common.h"
+
+namespace nlos {
+namespace {
+
+#ifndef NLOS_GRAD_NT
+#define NLOS_GRAD_NT 512
+#define NLOS_GRAD_WPS 4
+#endif
+template <int FEAT, int MODE, bool NC = false>
+__global__ __launch_bounds__(NLOS_GRAD_NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) {
+    extern __shared__ double s_mem[];       // [ticket (8 B)][diff row T][tap tables 3K+2][grad 3V][masks][bases][live]
+    int* s_next = reinterpret_cast<int*>(s_mem);
+    const int T = a.sp.nbins;
+    const int K = a.K;
+    const int F = a.sc.F, V = a.sc.V;
+    const int nblocks = (F + 63) >> 6;
+    double* s_diff = s_mem + 1;             // [T]
+    double* s_delta = s_diff + T;           // [K]
+    double* s_p0 = s_delta + K;             // [K+1]
+    double* s_p1 = s_p0 + K + 1;            // [K+1]
+    double* s_grad = s_p1 + K + 1;          // [3V] when lds_grad
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(s_grad + (((MODE == 0 || MODE == 4) && a.lds_grad) ? 3 * V : 0));
+    uint32_t* s_base = reinterpret_cast<uint32_t*>(s_mask + nblocks);              // [nblocks+1]
+    uint16_t* s_live = reinterpret_cast<uint16_t*>(s_base + ((nblocks + 2) & ~1));   // [F] sorted face slots (compact only)
+    const int spt = a.sp.spt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int Ltot = a.src.total_sources > 0 ? a.src.total_sources : a.src.L;
+    const double lbd = (double)a.sp.lb, resd = (double)a.sp.res, inv_res = 1.0 / resd;
+
+    if (MODE == 4) {
+        // jitter taps: s_delta <- (float) jitter_weight, s_p0 <- jitter_grad
+        for (int i = threadIdx.x; i < K; i += blockDim.x) { s_delta[i] = (double)(float)a.tap_w[i]; s_p0[i] = a.tap_g[i]; }
+    } else {
+        for (int i = threadIdx.x; i < K; i += blockDim.x) s_delta[i] = a.tap_delta[i];
+        for (int i = threadIdx.x; i <= K; i += blockDim.x) { s_p0[i] = a.tap_p0[i]; s_p1[i] = a.tap_p1[i]; }
+    }
+    if ((MODE == 0 || MODE == 4) && a.lds_grad)
+        for (int i = threadIdx.x; i < 3 * V; i += blockDim.x) s_grad[i] = 0.0;
+    double scalar_acc = 0.0;
+    TapTables tt;
+    tt.delta = s_delta; tt.p0 = s_p0; tt.p1 = s_p1; tt.K = K; tt.two_rs = a.two_rs; tt.r_over_res = a.r_over_res;
+
+    for (int l = blockIdx.x; l < a.src.L; l += gridDim.x) {
+        __syncthreads();                    // previous source done with s_diff
+        for (int i = threadIdx.x; i < T; i += blockDim.x) s_diff[i] = a.diff[(size_t)l * T + i];
+        if (threadIdx.x == 0) *s_next = 0;
+        // faces with at least one accepted sample, compacted in order (pass 1 left the masks)
+        for (int b = wave; b < nblocks; b += nwaves) {
+            const int j = (b << 6) + lane;
+            uint32_t any = 0;
+            if (j < F) {
+                const uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
+                for (int wi = 0; wi < a.vis_words; ++wi) any |= visp[(size_t)wi * F];
+            }
+            const unsigned long long m = __ballot(any != 0u);
+            if (lane == 0) s_mask[b] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            // wave 0: exclusive scan of the per-block counts
+            uint32_t run = 0;
+            for (int b0 = 0; b0 < nblocks; b0 += 64) {
+                const int b = b0 + lane;
+                uint32_t n = b < nblocks ? (uint32_t)__popcll(s_mask[b]) : 0u;
+                uint32_t incl = n;
+                for (int off = 1; off < 64; off <<= 1) {
+                    uint32_t v = __shfl_up(incl, off);
+                    if (lane >= off) incl += v;
+                }
+                if (b < nblocks) s_base[b] = run + incl - n;
+                run += __shfl(incl, 63);
+            }
+            if (lane == 0) s_base[nblocks] = run;
+        }
+        __syncthreads();
+        for (int b = wave; b < nblocks; b += nwaves) {
+            const unsigned long long m = s_mask[b];
+            if (a.compact && ((m >> lane) & 1ull))
+                s_live[s_base[b] + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((b << 6) + lane);
+        }
+        __syncthreads();
+        const int n_live = a.compact ? (int)s_base[nblocks] : F;
+        const int live_blocks = (n_live + 63) >> 6;
+        const V3 o = ld3(a.src.origin + 3 * (size_t)l);
+        const V3 on = ld3(a.src.normal + 3 * (size_t)l);
+        const V3 ob = NC ? ld3(a.src.sensor + 3 * (size_t)l) : o;
+        const V3 onb = NC ? ld3(a.src.sensor_normal + 3 * (size_t)l) : on;
+        const uint64_t lg = (uint64_t)(a.src.source_offset + l);
+
+        for (;;) {
+            const int b = wave_ticket(s_next);
+            if (b >= live_blocks) break;
+            const int li = (b << 6) + lane;
+            if (li >= n_live) continue;
+            const int j = a.compact ? (int)s_live[li] : li;
+            const uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
+            const Face f = load_face(a.sc.facerec, j);
+            if (MODE == 3 && f.i0 != a.vertex_num && f.i1 != a.vertex_num && f.i2 != a.vertex_num) continue;
+            const Tri tr = load_tri(a.sc.tris, j);
+            const uint64_t kbase = (lg * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
+            double acc[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) acc[q] = 0.0;
+            double sacc = 0.0;
+
+            for (int wi = 0; wi < a.vis_words; ++wi) {
+                uint32_t word = visp[(size_t)wi * F];
+                while (word) {
+                    const int bit = __ffs(word) - 1;
+                    word &= word - 1;
+                    const int s = (wi << 5) + bit;
+                    if (NC) {
+                        // row N: two legs, d(d1 + d2)/dp = dirA + dirB; P1 carries the confocal factor 2
+                        GeoNC gc;
+                        float tA, tB;
+                        if (!sample_geo_nc<FEAT>(f, tr, o, ob, a.sp.seed, kbase + (uint64_t)s, a.sp.lb, a.sp.ub,
+                                                 a.sc.vertex_normal, a.sc.albedo, gc, tA, tB))
+                            continue;
+                        GVec gv;
+                        grad_vectors_nc<FEAT>(f, gc, on, onb, a.normal_term, gv);
+                        const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
+                        const V3 ce[3] = {cross(gv.t2, e0), cross(gv.t2, e1), cross(gv.t2, e2)};
+                        double s0, s1;
+                        grouped_taps(tt, s_diff, T, (double)(gc.d1 + gc.d2), lbd, resd, inv_res, s0, s1);
+                        const V3 di = ((gc.dirA + gc.dirB) * 0.5f) * gv.inten_f;
+                        const float bw[3] = {gc.u, gc.v, gc.w};
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            V3 A1 = gv.t1 * bw[q] + ce[q];
+                            V3 A2 = di * bw[q];
+                            acc[3 * q + 0] += (double)A1.x * s0 + (double)A2.x * s1;
+                            acc[3 * q + 1] += (double)A1.y * s0 + (double)A2.y * s1;
+                            acc[3 * q + 2] += (double)A1.z * s0 + (double)A2.z * s1;
+                        }
+                        continue;
+                    }
+                    Geo g;
+                    float t_self;
+                    if (!sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, a.sp.lb, a.sp.ub,
+                                          a.sc.vertex_normal, a.sc.albedo, g, t_self))
+                        continue;   // cannot happen: pass 1 accepted this sample with the same arithmetic
+                    const double twoh = (double)(2.0f * g.h);
+                    if (MODE == 1 || MODE == 2) {
+                        // rows A / GGX alpha: scalar gradients (literal tap loop, double weights)
+                        float c2 = dot(on, g.dir);
+                        float c3 = dot(g.n, -g.dir);
+                        if (c2 < 0) c2 = 0;
+                        if (c3 < 0) c3 = 0;
+                        float ff = c2 * c3 / g.h / g.h;
+                        double g0;
+                        if (MODE == 2) g0 = (double)(g.alb * ff * ff * ggx_eval_adiff(a.sp.ggx_alpha, dot(g.n, -g.dir)));
+                        else g0 = (double)(ff * ff);
+                        double s0 = 0.0;
+                        for (int i = 0; i < K; ++i) {
+                            int bin = tap_bin(twoh, s_delta[i], lbd, resd, inv_res);
+                            if (bin >= 0 && bin < T) s0 += a.tap_w[i] * (-2) * s_diff[bin];
+                        }
+                        sacc += (double)f.area * g0 * s0 / (double)spt;
+                        continue;
+                    }
+                    GVec gv;
+                    grad_vectors<FEAT>(f, g, on, a.normal_term, a.v1_style, a.sp.ggx_alpha, gv);
+                    const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
+                    const V3 ce0 = cross(gv.t2, e0), ce1 = cross(gv.t2, e1), ce2 = cross(gv.t2, e2);
+                    if (MODE == 3) {
+                        // single-vertex per-bin gradient: output indexed by the tap's bin
+                        V3 ce; float bw;
+                        if (a.vertex_num == f.i0) { ce = ce0; bw = g.u; }
+                        else if (a.vertex_num == f.i1) { ce = ce1; bw = g.v; }
+                        else { ce = ce2; bw = g.w; }
+                        for (int i = 0; i < K; ++i) {
+                            int bin = tap_bin(twoh, s_delta[i], lbd, resd, inv_res);
+                            if (bin < 0 || bin >= T) continue;
+                            V3 gg = g.dir * (float)a.tap_g[i];
+                            V3 q = ((gv.t1 + gg * gv.inten_f) * bw + ce) * (float)a.tap_w[i];
+                            double sc = 1.0 / ((double)spt * (double)Ltot);
+                            unsafeAtomicAdd(&a.out[3 * bin + 0], (double)(f.area * q.x) * sc);
+                            unsafeAtomicAdd(&a.out[3 * bin + 1], (double)(f.area * q.y) * sc);
+                            unsafeAtomicAdd(&a.out[3 * bin + 2], (double)(f.area * q.z) * sc);
+                        }
+                        continue;
+                    }
+                    // MODE 0: the K-tap loop factors into two scalar sums per sample:
+                    //   sum_i (t1*b + t2 x e) w_i d_i  +  b * I * dir * sum_i g_i w_i d_i
+                    double s0, s1;
+                    V3 di;
+                    if (MODE == 4) {
+                        // jitter/transient_and_gradient.cpp:944-969: tap i -> bin b0 + (i - offset),
+                        //   g = (t1 w_i + jitter_grad_i * I * (-2) * dir / res) * b + (t2 x e) w_i
+                        const int b0 = (int)floorf((2.0f * g.h - a.sp.lb) / a.sp.res) - a.two_rs;
+                        const double m2i = (double)gv.inten_f * (-2);
+                        s0 = 0.0;
+                        s1 = 0.0;
+                        const int i0 = max(0, -b0), i1 = min(K, T - b0);
+                        for (int i = i0; i < i1; ++i) {
+                            const float dd = (float)((-2) * s_diff[b0 + i]);
+                            s0 += (double)((float)s_delta[i] * dd);
+                            s1 += (double)(((float)(s_p0[i] * m2i) / a.sp.res) * dd);
+                        }
+                        di = g.dir;
+                    } else {
+                        grouped_taps(tt, s_diff, T, twoh, lbd, resd, inv_res, s0, s1);
+                        di = g.dir * gv.inten_f;
+                    }
+                    const float bw[3] = {g.u, g.v, g.w};
+                    const V3 ce[3] = {ce0, ce1, ce2};
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        V3 A1 = gv.t1 * bw[q] + ce[q];
+                        V3 A2 = di * bw[q];
+                        acc[3 * q + 0] += (double)A1.x * s0 + (double)A2.x * s1;
+                        acc[3 * q + 1] += (double)A1.y * s0 + (double)A2.y * s1;
+                        acc[3 * q + 2] += (double)A1.z * s0 + (double)A2.z * s1;
+                    }
+                }
+            }
+            if (MODE == 0 || MODE == 4) {
+                const double sc = (double)f.area / (double)spt;
+                const int vi[3] = {f.i0, f.i1, f.i2};
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        double val = acc[3 * q + c] * sc;
+                        if (a.lds_grad) unsafeAtomicAdd(&s_grad[3 * vi[q] + c], val);
+                        else unsafeAtomicAdd(&a.out[3 * (size_t)vi[q] + c], val / (double)Ltot);
+                    }
+                }
+            } else if (MODE == 1 || MODE == 2) {
+                scalar_acc += sacc;
+            }
+        }
+    }
+    __syncthreads();
+    if ((MODE == 0 || MODE == 4) && a.lds_grad) {
+        const double invL = 1.0 / (double)Ltot;
+        for (int i = threadIdx.x; i < 3 * V; i += blockDim.x) {
+            double v = s_grad[i];
+            if (v != 0.0) unsafeAtomicAdd(&a.out[i], v * invL);
+        }
+    }
+    if (MODE == 1 || MODE == 2) {
+        for (int off = 32; off > 0; off >>= 1) scalar_acc += __shfl_down(scalar_acc, off);
+        if (lane == 0 && scalar_acc != 0.0) unsafeAtomicAdd(&a.out[0], scalar_acc / (double)Ltot);
+    }
+}
+
+// ------------------------------------------------- gradient, large meshes (face-major)
+// When 3V doubles do not fit LDS, k_gradient above falls back to nine global atomics per (source, face)
+// pair -- 74 M of them per step at F = 20 k, executed memory-side across the eight XCDs (4.7 ms).  This
+// variant turns the loop nest around: a workgroup owns a CHUNK of kFmChunk consecutive (Morton-sorted)
+// faces and a group of sources, keeps the nine sums of every face of the chunk in LDS across all its
+// sources (ds_add_f64, one writer lane per item), and touches the vertex gradient only once per face at
+// the end.  Per batch of kFmBatch sources it loads the residual rows, compacts the (source, face) items
+// with accepted samples into an LDS list (ballot + one LDS counter) and hands them to the lanes densely.
+// Same per-sample arithmetic as k_gradient<FEAT, 0>; only the fp64 summation order differs.
+constexpr int kFmChunk = 512, kFmBatch = 4, kFmThreads = 256;
+
+template <int FEAT>
+__global__ __launch_bounds__(kFmThreads) void k_gradient_fm(GradientArgs a, int src_per_group) {
+    extern __shared__ double s_fm[];      // [acc 9*CHUNK][rows BATCH*T][delta K][p0 K+1][p1 K+1][list BATCH*CHUNK u16][ctl]
+    const int T = a.sp.nbins, K = a.K, F = a.sc.F;
+    double* s_acc = s_fm;
+    double* s_rows = s_acc + 9 * kFmChunk;
+    double* s_delta = s_rows + kFmBatch * T;
+    double* s_p0 = s_delta + K;
+    double* s_p1 = s_p0 + K + 1;
+    uint16_t* s_list = reinterpret_cast<uint16_t*>(s_p1 + K + 1);
+    int* s_cnt = reinterpret_cast<int*>(s_list + kFmBatch * kFmChunk);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int f0 = blockIdx.x * kFmChunk, nf = min(kFmChunk, F - f0);
+    const int l0 = blockIdx.y * src_per_group, l1 = min(l0 + src_per_group, a.src.L);
+    const int spt = a.sp.spt;
+    const int Ltot = a.src.total_sources > 0 ? a.src.total_sources : a.src.L;
+    const double lbd = (double)a.sp.lb, resd = (double)a.sp.res, inv_res = 1.0 / resd;
+    for (int i = tid; i < 9 * kFmChunk; i += kFmThreads) s_acc[i] = 0.0;
+    for (int i = tid; i < K; i += kFmThreads) s_delta[i] = a.tap_delta[i];
+    for (int i = tid; i <= K; i += kFmThreads) { s_p0[i] = a.tap_p0[i]; s_p1[i] = a.tap_p1[i]; }
+    TapTables tt;
+    tt.delta = s_delta; tt.p0 = s_p0; tt.p1 = s_p1; tt.K = K; tt.two_rs = a.two_rs; tt.r_over_res = a.r_over_res;
+
+    for (int lb0 = l0; lb0 < l1; lb0 += kFmBatch) {
+        const int nb = min(kFmBatch, l1 - lb0);
+        __syncthreads();                                   // previous batch done with rows / list
+        for (int i = tid; i < nb * T; i += kFmThreads) s_rows[i] = a.diff[(size_t)lb0 * T + i];
+        if (tid == 0) *s_cnt = 0;
+        __syncthreads();
+        // (source, face) items of this batch with at least one accepted sample
+        for (int it = tid; it < nb * kFmChunk; it += kFmThreads) {
+            const int bl = it / kFmChunk, jl = it - bl * kFmChunk;
+            uint32_t any = 0;
+            if (jl < nf) {
+                const uint32_t* visp = a.vis + ((size_t)(lb0 + bl) * a.vis_words) * F + f0 + jl;
+                for (int wi = 0; wi < a.vis_words; ++wi) any |= visp[(size_t)wi * F];
+            }
+            const unsigned long long m = __ballot(any != 0u);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(s_cnt, __popcll(m));
+            base = __shfl(base, 0);
+            if (any) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((bl << 12) | jl);
+        }
+        __syncthreads();
+        const int n_items = *s_cnt;
+        for (int it = tid; it < n_items; it += kFmThreads) {
+            const int code = s_list[it];
+            const int bl = code >> 12, jl = code & 0xFFF;
+            const int l = lb0 + bl, j = f0 + jl;
+            const double* s_diff = s_rows + bl * T;
+            const Face f = load_face(a.sc.facerec, j);
+            const Tri tr = load_tri(a.sc.tris, j);
+            const V3 o = ld3(a.src.origin + 3 * (size_t)l);
+            const V3 on = ld3(a.src.normal + 3 * (size_t)l);
+            const uint64_t kbase = ((uint64_t)(a.src.source_offset + l) * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
+            const uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
+            double acc[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) acc[q] = 0.0;
+            for (int wi = 0; wi < a.vis_words; ++wi) {
+                uint32_t word = visp[(size_t)wi * F];
+                while (word) {
+                    const int bit = __ffs(word) - 1;
+                    word &= word - 1;
+                    Geo g;
+                    float t_self;
+                    if (!sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)((wi << 5) + bit), a.sp.lb, a.sp.ub,
+                                          a.sc.vertex_normal, a.sc.albedo, g, t_self))
+                        continue;
+                    GVec gv;
+                    grad_vectors<FEAT>(f, g, on, a.normal_term, a.v1_style, a.sp.ggx_alpha, gv);
+                    const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
+                    const V3 ce[3] = {cross(gv.t2, e0), cross(gv.t2, e1), cross(gv.t2, e2)};
+                    double s0, s1;
+                    grouped_taps(tt, s_diff, T, (double)(2.0f * g.h), lbd, resd, inv_res, s0, s1);
+                    const V3 di = g.dir * gv.inten_f;
+                    const float bw[3] = {g.u, g.v, g.w};
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const V3 A1 = gv.t1 * bw[q] + ce[q];
+                        const V3 A2 = di * bw[q];
+                        acc[3 * q + 0] += (double)A1.x * s0 + (double)A2.x * s1;
+                        acc[3 * q + 1] += (double)A1.y * s0 + (double)A2.y * s1;
+                        acc[3 * q + 2] += (double)A1.z * s0 + (double)A2.z * s1;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q) unsafeAtomicAdd(&s_acc[9 * jl + q], acc[q]);
+        }
+    }
+    __syncthreads();
+    // one pass over the chunk: scale and scatter to the vertices
+    for (int jl = tid; jl < nf; jl += kFmThreads) {
+        const Face f = load_face(a.sc.facerec, f0 + jl);
+        if (f.degenerate) continue;
+        const double sc = (double)f.area / (double)spt / (double)Ltot;
+        const int vi[3] = {f.i0, f.i1, f.i2};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double val = s_acc[9 * jl + 3 * q + c];
+                if (val != 0.0) unsafeAtomicAdd(&a.out[3 * (size_t)vi[q] + c], val * sc);
+            }
+    }
+}
+
+template <int FEAT>
+bool gradient_fm_launch(const GradientArgs& a, hipStream_t stream) {
+    // only the plain vertex gradient of meshes whose 3V accumulator cannot live in LDS
+    if (a.mode != 0 || a.src.sensor || a.sp.nbins * kFmBatch > 8192) return false;
+    const size_t lds = ((size_t)9 * kFmChunk + (size_t)kFmBatch * a.sp.nbins + 3 * (size_t)a.K + 2) * sizeof(double) +
+                       (size_t)kFmBatch * kFmChunk * 2 + 16;
+    if (lds > 80 * 1024) return false;
+    const int nchunks = (a.sc.F + kFmChunk - 1) / kFmChunk;
+    // enough workgroups to fill the chip (256 CUs x 2), sources in multiples of the batch
+    int groups = (1024 + nchunks - 1) / nchunks;
+    int per = (a.src.L + groups - 1) / groups;
+    per = ((per + kFmBatch - 1) / kFmBatch) * kFmBatch;
+    if (per < kFmBatch) per = kFmBatch;
+    groups = (a.src.L + per - 1) / per;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient_fm<FEAT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient_fm<FEAT>), dim3(nchunks, groups), dim3(kFmThreads), lds, stream, a, per);
+    return true;
+}
+
+template <int FEAT, int MODE>
+void gradient_launch2(const GradientArgs& a, int grid, size_t lds, hipStream_t stream) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, MODE>), dim3(grid), dim3(NLOS_GRAD_NT), lds, stream, a);
+}
+
+template <int FEAT>
+void gradient_launch(const GradientArgs& a, int grid, size_t lds, hipStream_t stream) {
+    if (a.src.sensor) {
+        if constexpr ((FEAT & FEAT_GGX) == 0) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, 0, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, 0, true>), dim3(grid), dim3(NLOS_GRAD_NT), lds, stream, a);
+        }
+        return;
+    }
+    switch (a.mode) {
+        case 0: gradient_launch2<FEAT, 0>(a, grid, lds, stream); break;
+        case 1: gradient_launch2<FEAT, 1>(a, grid, lds, stream); break;
+        case 2: gradient_launch2<FEAT, 2>(a, grid, lds, stream); break;
+        case 4:
+            if constexpr ((FEAT & (FEAT_GGX | FEAT_ALB)) == 0) gradient_launch2<FEAT, 4>(a, grid, lds, stream);
+            break;
+        default: gradient_launch2<FEAT, 3>(a, grid, lds, stream); break;
+    }
+}
+
+}  // namespace
+
+void launch_gradient(const GradientArgs& a_in, hipStream_t stream) {
+    if (a_in.src.L <= 0) return;
+    GradientArgs a = a_in;
+    const size_t nblk = ((size_t)a.sc.F + 63) / 64;
+    size_t lds = 8 + ((size_t)a.sp.nbins + 3 * (size_t)a.K + 2) * sizeof(double) + nblk * 8 + ((nblk + 2) & ~(size_t)1) * 4;
+    // compacted list of the faces with accepted samples (u16): skipped for meshes it cannot index / hold
+    a.compact = (a.sc.F <= 65535 && lds + 2 * (size_t)a.sc.F + 16 <= 64 * 1024) ? 1 : 0;
+    if (a.compact) lds += (2 * (size_t)a.sc.F + 15) & ~(size_t)15;
+    // per-workgroup 3V-double accumulator while it fits beside the rest (one workgroup per CU at worst)
+    const size_t acc = 3 * (size_t)a.sc.V * sizeof(double);
+    a.lds_grad = ((a.mode == 0 || a.mode == 4) && a_in.lds_grad && lds + acc <= 150 * 1024) ? 1 : 0;
+    if (!a.lds_grad && a.mode == 0 && !a.src.sensor && a_in.lds_grad) {
+        // large meshes: face-major variant (per-face sums in LDS across sources, one scatter per face)
+        bool done = false;
+        switch (feat_of(a.sc, a.sp)) {
+            case 0: done = gradient_fm_launch<0>(a, stream); break;
+            case 1: done = gradient_fm_launch<1>(a, stream); break;
+            case 2: done = gradient_fm_launch<2>(a, stream); break;
+            case 3: done = gradient_fm_launch<3>(a, stream); break;
+            case 4: done = gradient_fm_launch<4>(a, stream); break;
+            case 5: done = gradient_fm_launch<5>(a, stream); break;
+            case 6: done = gradient_fm_launch<6>(a, stream); break;
+            default: done = gradient_fm_launch<7>(a, stream); break;
+        }
+        if (done) return;
+    }
+    if (a.lds_grad) lds += acc;
+    // persistent workgroups: as many as can be co-resident (512 threads each, <= 128 VGPRs -> 4 per CU)
+    int per_cu = (int)(160 * 1024 / (lds + 64));
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    int grid = 256 * per_cu;
+    if (grid > a.src.L) grid = a.src.L;
+    switch (feat_of(a.sc, a.sp)) {
+        case 0: gradient_launch<0>(a, grid, lds, stream); break;
+        case 1: gradient_launch<1>(a, grid, lds, stream); break;
+        case 2: gradient_launch<2>(a, grid, lds, stream); break;
+        case 3: gradient_launch<3>(a, grid, lds, stream); break;
+        case 4: gradient_launch<4>(a, grid, lds, stream); break;
+        case 5: gradient_launch<5>(a, grid, lds, stream); break;
+        case 6: gradient_launch<6>(a, grid, lds, stream); break;
+        default: gradient_launch<7>(a, grid, lds, stream); break;
+    }
+}
+
+}  // namespace nlos

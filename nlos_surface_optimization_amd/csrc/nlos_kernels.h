@@ -82,6 +82,9 @@ struct ForwardArgs {
     int tiles_x, tiles_y, tile_cap;
 };
 void launch_forward(const ForwardArgs& a, hipStream_t stream);
+// the two back-ends behind launch_forward (forward_grid.hip returns false when the BVH back-end is needed)
+bool launch_forward_grid(const ForwardArgs& a, int rows_in_lds, hipStream_t stream);
+void launch_forward_bvh(const ForwardArgs& a, int rows_in_lds, hipStream_t stream);
 
 // refined-histogram Gaussian + fold (row FD, refine > 1)
 struct SmoothArgs {

@@ -1,0 +1,303 @@
+// render_common.h -- per-sample building blocks shared by the render kernels (internal header).
+//
+// Everything a (source, face, stratum) sample needs, restated once from the reference
+// (paths relative to transient_rendering_cython/):
+//   load_face / sample_geo     smoothed_transient/transient_and_gradient.cpp:157-159, :178-223 (rows S, I own-face part)
+//   sample_geo_nc              row N (non-confocal pairs; prototypes only in the reference)
+//   grad_vectors(_nc)          :944-966, ggx/transient_and_gradient.cpp:750-783 (t1, t2, intensity)
+//   tap_bin / grouped_taps     :973-999 (the K-tap loop, factored into two scalar sums)
+// The kernels live in forward_bvh.hip, forward_grid.hip, gradient.hip and render_kernels.hip.
+#pragma once
+#include "nlos_device.h"
+#include "nlos_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace nlos {
+namespace {
+
+constexpr int FEAT_VN = 1, FEAT_ALB = 2, FEAT_GGX = 4;
+
+struct Face {
+    V3 p0, p1, p2;
+    int fid, i0, i1, i2;
+    V3 fn;
+    float area;
+    bool degenerate;
+};
+
+__device__ __forceinline__ Face load_face(const float4* __restrict__ rec, int j) {
+    float4 a = rec[4 * j], b = rec[4 * j + 1], c = rec[4 * j + 2], d = rec[4 * j + 3];
+    Face f;
+    f.p0 = mk(a.x, a.y, a.z);
+    f.p1 = mk(a.w, b.x, b.y);
+    f.p2 = mk(b.z, b.w, c.x);
+    f.fid = __float_as_int(c.y);
+    f.i0 = __float_as_int(c.z);
+    f.i1 = __float_as_int(c.w);
+    f.i2 = __float_as_int(d.x);
+    // smoothed_transient/transient_and_gradient.cpp:157-159
+    V3 nr = cross(f.p1 - f.p0, f.p2 - f.p0);
+    f.area = sqrtf(dot(nr, nr)) / 2.0f;
+    f.degenerate = !(f.area > 0.0f);
+    f.fn = nr * (1.0f / (2.0f * f.area));
+    return f;
+}
+
+// per-sample geometry of an own-face hit
+struct Geo {
+    float u, v, w, h;
+    V3 dir, n;
+    float alb;
+};
+
+// Row S + the own-face part of row I: stratified sample -> ray -> hit on face j.
+// Returns false if the ray misses its own triangle (edge rounding) or the path
+// length is outside [lb/2, ub/2].
+template <int FEAT>
+__device__ __forceinline__ bool sample_geo(const Face& f, const Tri& tr, V3 o, uint64_t seed, uint64_t k,
+                                           float lb, float ub, const float* __restrict__ vn,
+                                           const float* __restrict__ alb, Geo& g, float& t_self) {
+    float S, T;
+    sample_st(seed, k, S, T);
+    float sq = sqrtf(T);
+    float u = 1 - sq;
+    float v = (1 - S) * sq;
+    float w = S * sq;
+    V3 p = bary(u, f.p0, v, f.p1, w, f.p2);
+    V3 d = p - o;
+    float rs = 1.0f / sqrtf(dot(d, d));
+    g.dir = d * rs;
+    float hu, hv;
+    if (!tri_test(tr, o, g.dir, t_self, hu, hv)) return false;
+    g.v = hu;
+    g.w = hv;
+    g.u = 1.0f - g.v - g.w;
+    V3 q = bary(g.u, f.p0, g.v, f.p1, g.w, f.p2);
+    V3 dq = q - o;
+    g.h = sqrtf(dot(dq, dq));
+    if (!((g.h <= ub / 2.0f) && (g.h >= lb / 2.0f))) return false;
+    g.n = f.fn;
+    if (FEAT & FEAT_VN) {
+        g.n = bary(g.u, ld3(vn + 3 * (size_t)f.i0), g.v, ld3(vn + 3 * (size_t)f.i1), g.w,
+                   ld3(vn + 3 * (size_t)f.i2));
+    }
+    g.alb = 1.0f;
+    if (FEAT & FEAT_ALB) g.alb = g.u * alb[f.i0] + g.v * alb[f.i1] + g.w * alb[f.i2];
+    return true;
+}
+
+__device__ __forceinline__ float emax0(float x) { return 0.0f < x ? x : 0.0f; }
+
+__device__ __forceinline__ int wave_ticket(int* counter) {
+    int b = 0;
+    if ((threadIdx.x & 63) == 0) b = atomicAdd(counter, 1);
+    return __builtin_amdgcn_readfirstlane(b);
+}
+
+// ------------------------------------------------------- forward, row N (pairs)
+// Non-confocal pair l = (laser a, sensor b).  No native reference kernel exists;
+// geometry follows the reference prototypes (transient_rendering_python/rendering.py:37-93: nearest
+// hit from the laser, second segment visible from the sensor, path d1 + d2) with the v2
+// conventions of rows F/G, so a == b gives the confocal rows bit for bit.
+struct GeoNC {
+    float u, v, w, d1, d2;
+    V3 dirA, dirB, n;
+    float alb;
+};
+
+template <int FEAT>
+__device__ __forceinline__ bool sample_geo_nc(const Face& f, const Tri& tr, V3 oa, V3 ob, uint64_t seed, uint64_t k,
+                                              float lb, float ub, const float* __restrict__ vn,
+                                              const float* __restrict__ alb, GeoNC& g, float& tA, float& tB) {
+    float S, T;
+    sample_st(seed, k, S, T);
+    float sq = sqrtf(T);
+    float u = 1 - sq;
+    float v = (1 - S) * sq;
+    float w = S * sq;
+    V3 p = bary(u, f.p0, v, f.p1, w, f.p2);
+    V3 dA = p - oa;
+    g.dirA = dA * (1.0f / sqrtf(dot(dA, dA)));
+    float hu, hv;
+    if (!tri_test(tr, oa, g.dirA, tA, hu, hv)) return false;
+    g.v = hu;
+    g.w = hv;
+    g.u = 1.0f - g.v - g.w;
+    V3 qA = bary(g.u, f.p0, g.v, f.p1, g.w, f.p2);
+    V3 eA = qA - oa;
+    g.d1 = sqrtf(dot(eA, eA));
+    V3 dB = p - ob;
+    g.dirB = dB * (1.0f / sqrtf(dot(dB, dB)));
+    float bu, bv;
+    if (!tri_test(tr, ob, g.dirB, tB, bu, bv)) return false;
+    V3 qB = bary(1.0f - bu - bv, f.p0, bu, f.p1, bv, f.p2);
+    V3 eB = qB - ob;
+    g.d2 = sqrtf(dot(eB, eB));
+    const float tot = g.d1 + g.d2;
+    if (!((tot <= ub) && (tot >= lb))) return false;
+    g.n = f.fn;
+    if (FEAT & FEAT_VN) {
+        g.n = bary(g.u, ld3(vn + 3 * (size_t)f.i0), g.v, ld3(vn + 3 * (size_t)f.i1), g.w,
+                   ld3(vn + 3 * (size_t)f.i2));
+    }
+    g.alb = 1.0f;
+    if (FEAT & FEAT_ALB) g.alb = g.u * alb[f.i0] + g.v * alb[f.i1] + g.w * alb[f.i2];
+    return true;
+}
+
+// ------------------------------------------------------------------- gradient
+// Per accepted sample: vectors t1, t2 and the intensity
+// (smoothed_transient/transient_and_gradient.cpp:944-966, ggx/...:750-783).
+struct GVec { V3 t1, t2; float inten_f; };
+
+template <int FEAT>
+__device__ __forceinline__ void grad_vectors(const Face& f, const Geo& g, V3 on, int normal_term, int v1_style,
+                                             float alpha, GVec& out) {
+    float c2 = dot(on, g.dir);
+    float c3 = dot(g.n, -g.dir);
+    if (c2 < 0) c2 = 0;
+    if (c3 < 0) c3 = 0;
+    float ff = c2 * c3 / g.h / g.h;
+    float h2 = g.h * g.h, h4 = h2 * h2, h5 = h4 * g.h;
+    V3 inner = ((on * c3) - (g.n * c2)) + ((((-g.dir) * 4.0f) * c2) * c3);
+    V3 t1, gn = mk(0, 0, 0);
+    if (FEAT & FEAT_GGX) {
+        V3 wv = -g.dir;
+        float nw = dot(g.n, wv);
+        float brdf = ggx_eval(alpha, nw);
+        float s = ggx_eval_nwsdiff(alpha, nw);
+        V3 dn = wv * s, dw = g.n * s;
+        V3 dx = (-dw) + ((g.dir * dot(g.dir, dw)) * (1.0f / g.h));
+        out.inten_f = (float)(double)(g.alb * ff * ff * brdf);
+        V3 t11 = inner * (2 * c2 * c3);
+        t11 = t11 * (1.0f / h5);
+        t11 = t11 * brdf;
+        t1 = t11 + dx * (ff * ff);
+        if (normal_term) {
+            gn = ((((g.dir * -2.0f) * c3) * c2) * c2) * brdf;
+            gn = gn * (1.0f / h4);
+            gn = gn + dn * (ff * ff);
+            float ct = dot(gn, g.n);
+            gn = gn - g.n * ct;
+        }
+    } else {
+        out.inten_f = g.alb * ff * ff;
+        float sc = v1_style ? (2 * c2 * c3) : (2 * g.alb * c2 * c3);
+        t1 = inner * sc;
+        t1 = t1 * (1.0f / h5);
+        if (normal_term) {
+            float s0 = v1_style ? -2.0f : (-2 * g.alb);
+            gn = (((g.dir * s0) * c3) * c2) * c2;
+            gn = gn * (1.0f / h4);
+            float ct = dot(gn, g.n);
+            gn = gn - g.n * ct;
+        }
+    }
+    V3 t2 = g.n * out.inten_f;
+    t2 = (t2 + gn) * (1.0f / (2 * f.area));
+    out.t1 = t1;
+    out.t2 = t2;
+}
+
+// Row N: t1 = alb (ff_b grad ff_a + ff_a grad ff_b), grad ff = (n_o c3 - n c2 - 4 dir c2 c3) / d^3;
+// normal term dI/dn projected as in the confocal rows
+template <int FEAT>
+__device__ __forceinline__ void grad_vectors_nc(const Face& f, const GeoNC& g, V3 na, V3 nb, int normal_term, GVec& out) {
+    float c2a = dot(na, g.dirA), c3a = dot(g.n, -g.dirA);
+    float c2b = dot(nb, g.dirB), c3b = dot(g.n, -g.dirB);
+    if (c2a < 0) c2a = 0;
+    if (c3a < 0) c3a = 0;
+    if (c2b < 0) c2b = 0;
+    if (c3b < 0) c3b = 0;
+    const float ffa = c2a * c3a / g.d1 / g.d1, ffb = c2b * c3b / g.d2 / g.d2;
+    const V3 ia = ((na * c3a) - (g.n * c2a)) + ((((-g.dirA) * 4.0f) * c2a) * c3a);
+    const V3 ib = ((nb * c3b) - (g.n * c2b)) + ((((-g.dirB) * 4.0f) * c2b) * c3b);
+    const V3 ga = ia * (1.0f / ((g.d1 * g.d1) * g.d1));
+    const V3 gb = ib * (1.0f / ((g.d2 * g.d2) * g.d2));
+    out.inten_f = g.alb * ffa * ffb;
+    out.t1 = ((ga * ffb) + (gb * ffa)) * g.alb;
+    V3 gn = mk(0, 0, 0);
+    if (normal_term) {
+        gn = (g.dirA * c3b) + (g.dirB * c3a);
+        gn = gn * (-(g.alb * c2a * c2b));
+        gn = gn * (1.0f / ((g.d1 * g.d1) * (g.d2 * g.d2)));
+        float ct = dot(gn, g.n);
+        gn = gn - g.n * ct;
+    }
+    V3 t2 = g.n * out.inten_f;
+    out.t2 = (t2 + gn) * (1.0f / (2 * f.area));
+}
+
+// bin of tap i: floor((2h + delta_i - lb) / res) in double
+// (smoothed_transient/transient_and_gradient.cpp:975-976); reciprocal multiply with an
+// exact-division fallback when the quotient is within 1e-9 of an integer.
+__device__ __forceinline__ int tap_bin(double twoh, double delta, double lb, double res, double inv_res) {
+    double num = (twoh + delta) - lb;
+    double x = num * inv_res;
+    double fl = floor(x);
+    double fr = x - fl;
+    if (fr < 1e-9 || fr > 1.0 - 1e-9) fl = floor(num / res);
+    return (int)fl;
+}
+
+// Grouped taps (mode 0).  bin_i is non-decreasing in i and takes at most 4*sigma_bin+2 distinct
+// values, so sum_i w_i d[bin_i] = sum_b d[b] * (P0[end_b] - P0[start_b]) with host-side prefix sums
+// P0 = cumsum(float(w)), P1 = cumsum(g * float(w)).  The boundary tap of every bin is located from
+// the closed form and then verified with the exact per-tap bin formula, so tap->bin assignment is
+// identical to the reference's literal loop (the exact check runs only when the closed-form boundary
+// falls within 1e-4 of a tap, 100x the rounding of the tap offsets).
+struct TapTables {
+    const double* delta;   // [K]
+    const double* p0;      // [K+1]
+    const double* p1;      // [K+1]
+    int K, two_rs;
+    double r_over_res;     // refine / res
+};
+
+__device__ __forceinline__ void grouped_taps(const TapTables& tt, const double* __restrict__ s_diff, int T,
+                                             double twoh, double lbd, double resd, double inv_res,
+                                             double& s0, double& s1) {
+    s0 = 0.0;
+    s1 = 0.0;
+    const int K = tt.K;
+    const int b_first = tap_bin(twoh, tt.delta[0], lbd, resd, inv_res);
+    const int b_last = tap_bin(twoh, tt.delta[K - 1], lbd, resd, inv_res);
+    int i_start = 0;
+    for (int b = b_first; b <= b_last; ++b) {
+        int ie = K;
+        if (b < b_last) {
+            // first tap whose bin exceeds b: delta_i >= (b+1)*res + lb - 2h
+            const double thr = ((double)(b + 1) * resd + lbd) - twoh;
+            const double y = thr * tt.r_over_res;          // boundary in (continuous) tap index, minus two_rs
+            const double yc = ceil(y);
+            int ic = (int)yc + tt.two_rs;
+            ic = max(i_start, min(K, ic));
+            // delta_i carries the fp32 rounding of (i - two_rs) * res / refine (<= ~1e-6 taps): the closed
+            // form is the reference's per-tap assignment unless the boundary is that close to a tap
+            if (yc - y < 1e-4 || y - (yc - 1.0) < 1e-4) {
+                while (ic > i_start && tap_bin(twoh, tt.delta[ic - 1], lbd, resd, inv_res) > b) --ic;
+                while (ic < K && tap_bin(twoh, tt.delta[ic], lbd, resd, inv_res) <= b) ++ic;
+            }
+            ie = ic;
+        }
+        if (b >= 0 && b < T && ie > i_start) {
+            double dd = (double)(float)((-2) * s_diff[b]);
+            s0 += dd * (tt.p0[ie] - tt.p0[i_start]);
+            s1 += dd * (tt.p1[ie] - tt.p1[i_start]);
+        }
+        i_start = ie;
+    }
+}
+
+// MODE 0: per-vertex gradient [V,3]; 1: scalar d/d albedo; 2: scalar d/d alpha (GGX);
+//      3: single-vertex per-bin gradient [T,3]
+// two 512-thread workgroups per CU (LDS: ~76 KB each) need <= 128 VGPRs
+inline int feat_of(const SceneView& sc, const SampleParams& sp) {
+    return (sc.vertex_normal ? FEAT_VN : 0) | (sc.albedo ? FEAT_ALB : 0) | (sp.use_ggx ? FEAT_GGX : 0);
+}
+
+
+}  // namespace
+}  // namespace nlos
