@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--subdivide", type=int, default=0,
                     help="side measurement (not the metric): 1->4 midpoint subdivision passes of the mesh (F x 4^n)")
+    ap.add_argument("--faces", type=int, default=0,
+                    help="side measurement: subdivide once, then vertex-cluster down to about this many faces")
     ap.add_argument("--non-confocal", action="store_true",
                     help="row N side measurement (not the metric): every source becomes a (laser, sensor) pair, "
                          "sensor = laser + (0.05, -0.03, 0)")
@@ -135,6 +137,11 @@ def main():
     if args.subdivide > 0:
         from nlos_surface_optimization_amd import mesh_io
         v_np, f_np = mesh_io.subdivide(v_np, f_np, args.subdivide)
+    if args.faces > 0:
+        from nlos_surface_optimization_amd import mesh_io
+        v_np, f_np = mesh_io.subdivide(v_np, f_np, 1)
+        v_np, f_np = mesh_io.decimate_to(v_np, f_np, args.faces)
+        v_np, f_np = np.ascontiguousarray(v_np, np.float32), np.ascontiguousarray(f_np, np.int32)
     F, V = f_np.shape[0], v_np.shape[0]
     T = args.bins
     lb, ub, res = 0.625, 1.625, 1.0 / T          # exact in fp32 for T = 512 / 1024
@@ -233,14 +240,14 @@ def main():
             achieved = per_sample * local_samples / (kt[dom] * 1e-3) / 1e9
             pmc = load_pmc_traffic()
             traffic = None
-            if pmc and not args.non_confocal and not args.subdivide and pmc.get("kernel") == names[dom] and pmc.get("L") == L and pmc.get("F") == F:
+            if pmc and not args.non_confocal and not args.subdivide and not args.faces and pmc.get("kernel") == names[dom] and pmc.get("L") == L and pmc.get("F") == F:
                 traffic = pmc.get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_sample": per_sample,
                                "kernel_ms": {n: float(x) for n, x in zip(names, kt)},
                                "step_algorithmic_GBps": (200.0 + 72.0 / spt) * local_samples / (ms * 1e-3) / 1e9}
-        if world == 1 and not args.no_cpu_baseline and not args.forward_only and not args.non_confocal and not args.subdivide:
+        if world == 1 and not args.no_cpu_baseline and not args.forward_only and not args.non_confocal and not args.subdivide and not args.faces:
             out["cpu_baseline"] = cpu_baseline(v_np, f_np, origin_np, normal_np, lb, ub, res, args.num_sample,
                                                data.cpu().numpy())
         print(json.dumps(out))

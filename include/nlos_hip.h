@@ -245,7 +245,7 @@ typedef struct nlos_render_args {
                                    previous render on this ctx (same mesh, sources, samples, seed) */
     int32_t force_bvh;          /* 1: occlusion by BVH traversal only (default 0: per-source perspective
                                    grid in LDS, tiled over several workgroups per source for meshes beyond
-                                   ~7.4 k faces; identical results).  2 (diagnostic): tiled grid with a tiny
+                                   5.8 k faces; identical results).  2 (diagnostic): tiled grid with a tiny
                                    per-tile capacity, to exercise the tiles' overflow fallback */
     /* non-confocal pairs (the reference has only Python prototypes of it:
      * transient_rendering_python/rendering.py:8-93, mesh_optimization/rendering.py:739-797).

@@ -184,9 +184,10 @@ __global__ __launch_bounds__(512) void k_tile_bin(ForwardArgs a, int R) {
 // frame so that all workgroups of a source agree.  Rows and visibility words are combined with atomics
 // (the launcher zeroes them).  A tile whose subset overflows iterates over all faces and uses the BVH
 // query for its own samples; a source whose scene is not strictly in front is handled by tile 0 alone.
-// Tiles whose cell lists overflow the normal LDS share (two workgroups per CU) flag themselves and leave
-// before writing anything; a second launch (`pass` = 1) with one workgroup per CU and ~150 KB of LDS redoes
-// exactly those tiles (grazing views pile thousands of sliver triangles into a few tiles).
+// Workgroups (sources, or tiles) whose cell lists overflow the normal LDS share (two workgroups per CU) flag
+// themselves in a.retry and leave before binning anything; a second launch (`pass` = 1) with one workgroup
+// per CU and ~150 KB of LDS redoes exactly those (grazing views pile thousands of sliver triangles into a
+// few cells / tiles).
 template <int FEAT, int NCM = 0, bool TILED = false>
 __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows_in_lds, int R, int cap, int pass = 0) {
     // dynamic LDS: [ctl: ticket, bad, total, n_live (16 B)][row nbins f64][cells R*R+1 u32]
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     // (the bucketed live-face list lives in global scratch: it is read once per 64-face block)
     extern __shared__ double s_lds[];
     constexpr int IB = TILED ? kIdxBitsTiled : kIdxBits;
-    if (TILED && pass == 1 && a.tile_count[gridDim.x + blockIdx.x] == 0) return;     // only the flagged tiles
+    if (pass == 1 && a.retry[blockIdx.x] == 0) return;     // second launch: only the flagged workgroups
     int* s_ctl = reinterpret_cast<int*>(s_lds);      // 8 ints: ticket, bad, total entries, n_live, tile subset size
     double* s_row = s_lds + 4;
     const int nbins = a.sp.nbins;
@@ -380,8 +381,8 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
         if (tid == NT - 1) { s_ctl[2] = (int)s_scan[tid]; if ((int)s_scan[tid] > cap) s_ctl[1] = 1; }
     }
     __syncthreads();
-    if (TILED && pass == 0 && frame_ok && !ident && s_ctl[1] != 0) {
-        if (tid == 0) a.tile_count[gridDim.x + blockIdx.x] = 1;      // cell lists overflow: redo with the big-LDS launch
+    if (pass == 0 && a.retry && frame_ok && !(TILED && ident) && s_ctl[1] != 0) {
+        if (tid == 0) a.retry[blockIdx.x] = 1;      // cell lists overflow: redo with the big-LDS launch
         return;
     }
     FWD_STAMP();   // 2: scans
@@ -721,7 +722,10 @@ constexpr size_t kGridLdsBudget = 78 * 1024;
 template <int FEAT, int NCM = 0>
 bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
     if (a.force_bvh || a.tile_list || a.sc.F > 8191 || a.sc.F < 64) return false;     // 13-bit triangle index in the cell entries
-    int R = (int)lrintf(sqrtf(0.5f * (float)a.sc.F));
+#ifndef NLOS_GRID_RSCALE
+#define NLOS_GRID_RSCALE 0.5f
+#endif
+    int R = (int)lrintf(sqrtf(NLOS_GRID_RSCALE * (float)a.sc.F));
     R = std::min(std::max(R, 8), 96);
     const size_t nblk = ((size_t)a.sc.F + 63) / 64;
     const size_t R2 = ((size_t)R + 1) / 2;
@@ -732,11 +736,16 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
     if (fixed + 4 * 2 * (size_t)a.sc.F > kGridLdsBudget || !a.live) return false;      // want room for >= 2 entries per face
     size_t cap = (kGridLdsBudget - fixed) / 4;
     const size_t lds = fixed + cap * 4;
+    const size_t lds_big = 150 * 1024;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(a.retry ? lds_big : lds));
+    if (a.retry) (void)hipMemsetAsync(a.retry, 0, sizeof(int) * (size_t)a.src.L, stream);
     // one slot of slack: the walk reads entries in pairs and may touch the slot after the last list
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM>), dim3(a.src.L), dim3(512), lds, stream, a, rows_in_lds, R,
-                       (int)cap - 1);
+                       (int)cap - 1, 0);
+    if (a.retry)      // sources whose cell lists overflowed: once more with the whole CU's LDS
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM>), dim3(a.src.L), dim3(512), lds_big, stream, a, rows_in_lds,
+                           R, (int)((lds_big - fixed) / 4) - 1, 1);
     return true;
 }
 

@@ -454,11 +454,15 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.live = nullptr;
     fa.tile_list = nullptr;
     fa.tile_count = nullptr;
+    fa.retry = nullptr;
     fa.tiles_x = fa.tiles_y = fa.tile_cap = 0;
-    if (nF <= 7400 && a->force_bvh != 1) {
+    static const int tile_threshold = [] { const char* e = std::getenv("NLOS_TILE_THRESHOLD"); return e ? std::atoi(e) : 5800; }();
+    if (nF <= tile_threshold && a->force_bvh != 1) {
         rc = c->live.ensure(sizeof(uint16_t) * (size_t)(L > 0 ? L : 1) * nF + 16);
+        if (!rc) rc = c->tile_count.ensure(sizeof(int) * (size_t)(L > 0 ? L : 1) + 16);
         if (rc) return rc;
         fa.live = c->live.as<uint16_t>();
+        fa.retry = c->tile_count.as<int>();
     } else if (a->force_bvh != 1 && !a->sensor && mode != NLOS_MODE_INTENSITY && L > 0) {
         // tiled grid: ~3000 triangles per slope-space tile on average (small tiles leave the 512 threads idle); the densest tiles of a closed surface
         // (front + back side, several depth layers) hold up to ~4.5x the mean, and the subset capacity is bounded by
@@ -478,6 +482,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
             if (!rc) rc = c->tile_count.ensure(sizeof(int) * 2 * (size_t)L * tiles + 16);
             if (rc) return rc;
             fa.tile_count = c->tile_count.as<int>();
+            fa.retry = fa.tile_count + (size_t)L * tiles;
             fa.live = c->live.as<uint16_t>();
             fa.tile_list = c->tile_list.as<uint32_t>();
             fa.tiles_x = fa.tiles_y = side;

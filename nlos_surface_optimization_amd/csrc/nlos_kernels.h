@@ -78,8 +78,9 @@ struct ForwardArgs {
     // tiled grid (meshes beyond one workgroup's LDS): slope space is cut into tiles_x * tiles_y tiles, one
     // workgroup per (source, tile); tile_list holds each workgroup's triangle subset (tile_cap ids each)
     uint32_t* tile_list;     // [L * tiles, tile_cap] scratch or null
-    int* tile_count;         // [2, L * tiles]: subset sizes (may exceed tile_cap: overflow) filled by k_tile_bin; retry flags
+    int* tile_count;         // [L * tiles] subset sizes (may exceed tile_cap: overflow), filled by k_tile_bin
     int tiles_x, tiles_y, tile_cap;
+    int* retry;              // [workgroups] flags of the big-LDS second launch (grid kernels) or null
 };
 void launch_forward(const ForwardArgs& a, hipStream_t stream);
 // the two back-ends behind launch_forward (forward_grid.hip returns false when the BVH back-end is needed)
