@@ -306,6 +306,12 @@ int nlos_create_weighting(nlos_ctx *ctx, const double *data, int rows, int cols,
 int nlos_weighted_l2(nlos_ctx *ctx, const double *transient, const double *data, const double *weight,
                      int rows, int cols, double *out, void *stream);
 
+/* diagnostics: copy internal scratch of the last render to HOST memory (synchronises the device).
+ * what = 0: the visibility cache, uint32 [L, words, F] in Morton-sorted face order (needs
+ * keep_visibility or a gradient mode); what = 1: int32 [F] original face id of each sorted slot.
+ * Returns the number of bytes copied (<= max_bytes) or a negative status. */
+int64_t nlos_ctx_debug_read(nlos_ctx *ctx, int what, void *host_out, int64_t max_bytes);
+
 /* number of bins the reference computes in float32: ceil((ub-lb)/res) */
 int nlos_num_bins(float lower_bound, float upper_bound, float resolution);
 

@@ -102,6 +102,7 @@ SYMBOLS = {
     "nlos_streamed_render_normal_smoothing": (_I, [_P, _I, _P, _I, _P, _P, _P]),
     "nlos_streamed_render_curvature_grad": (_I, [_P, _I, _P, _I, _P]),
     "nlos_set_regulariser_overwrite": (None, [_I]),
+    "nlos_ctx_debug_read": (_I64, [_P, _I, _P, _I64]),
     "nlos_adam_modified_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_double, ctypes.c_double,
                                      ctypes.c_double, ctypes.c_double, ctypes.c_double, _P]),
     "nlos_create_weighting": (_I, [_P, _P, _I, _I, ctypes.c_double, _P, _P]),

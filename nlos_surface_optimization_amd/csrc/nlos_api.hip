@@ -688,6 +688,22 @@ int nlos_intersect(nlos_ctx* c, const float* origins, const float* dirs, int n_r
     return NLOS_OK;
 }
 
+int64_t nlos_ctx_debug_read(nlos_ctx* c, int what, void* host_out, int64_t max_bytes) {
+    if (!c || !host_out || max_bytes < 0) return -(int64_t)fail(NLOS_ERR_ARG, "nlos_ctx_debug_read: bad arguments");
+    DeviceGuard guard(c->device);
+    const DevBuf* b = what == 0 ? &c->vis : (what == 1 ? &c->face_id : nullptr);
+    if (!b || !b->p) return -(int64_t)fail(NLOS_ERR_ARG, "nlos_ctx_debug_read: nothing to read");
+    size_t n = 0;
+    if (what == 0) n = sizeof(uint32_t) * (size_t)c->vis_key.L * (size_t)((c->vis_key.spt + 31) / 32) * (size_t)c->vis_key.F;
+    else n = sizeof(int) * (size_t)c->built_F;
+    if (n > (size_t)max_bytes) n = (size_t)max_bytes;
+    if (n > b->cap) n = b->cap;
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(host_out, b->p, n, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return -(int64_t)fail(NLOS_ERR_HIP, std::string("nlos_ctx_debug_read: ") + hipGetErrorString(e));
+    return (int64_t)n;
+}
+
 int nlos_adam_modified_step(nlos_ctx* c, float* params, const double* grad_f64, const float* grad_f32, float* exp_avg,
                             float* exp_avg_sq, float* max_exp_avg_sq, const uint8_t* row_mask, int rows, int cols,
                             int step, double lr, double beta1, double beta2, double eps, double weight_decay,

@@ -227,6 +227,19 @@ class TransientRenderer:
         _lib.check(rc, "nlos_mesh_regulariser")
         return (val[0] if face_affinity is not None else None), grad
 
+    def debug_visibility(self, L, spt, F):
+        """Diagnostics: (visibility cache uint32 [L, words, F] in sorted-face order, original face id per
+        sorted slot) of the last render that kept it (keep_visibility=True or a gradient render)."""
+        import numpy as np
+        words = (spt + 31) // 32
+        vis = np.zeros((L, words, F), np.uint32)
+        fid = np.zeros(F, np.int32)
+        for what, arr in ((0, vis), (1, fid)):
+            n = self._lib.nlos_ctx_debug_read(self._h, what, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes)
+            if n != arr.nbytes:
+                raise _lib.NlosError("nlos_ctx_debug_read(%d) returned %d, expected %d" % (what, n, arr.nbytes))
+        return vis, fid
+
     def create_weighting_function(self, data, gamma=1.0):
         """exp_bunny/rendering.py:208-217 on a device tensor: (data/max + 0.1)^gamma, rescaled to sum to data.numel()."""
         _want(data, torch.float64, "data", 2)
