@@ -134,9 +134,9 @@ __device__ __forceinline__ SourceFrame source_frame(const float4* __restrict__ n
 // Tile binning for the tiled grid: one workgroup per source appends every triangle to the subset of each
 // slope-space tile its projected bounding box meets (with the rasteriser's margin).  O(F) per source -- the
 // tiles' workgroups then read their subset instead of scanning the whole mesh each.
-__global__ __launch_bounds__(512) void k_tile_bin(ForwardArgs a, int R) {
+__global__ __launch_bounds__(512) void k_tile_bin(ForwardArgs a, int R, int from_sensor) {
     const int l = blockIdx.x;
-    const V3 o = ld3(a.src.origin + 3 * (size_t)l);
+    const V3 o = ld3((from_sensor ? a.src.sensor : a.src.origin) + 3 * (size_t)l);
     const SourceFrame fr = source_frame(a.sc.nodes, o);
     if (!fr.ok) return;                                   // tile 0 handles such a source alone
     const int ntx = a.tiles_x, nty = a.tiles_y;
@@ -750,9 +750,11 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
 }
 
 // meshes beyond one workgroup's LDS: one workgroup per (source, slope-space tile)
-template <int FEAT>
+template <int FEAT, int NCM = 0>
 bool forward_tiled_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
-    if (a.force_bvh || !a.tile_list || !a.tile_count || !a.live || a.tiles_x * a.tiles_y > 1024 || a.tiles_x < 1 || a.tiles_y < 1 || a.mode_intensity || a.src.sensor) return false;
+    if (a.force_bvh || !a.tile_list || !a.tile_count || !a.live || a.tiles_x * a.tiles_y > 1024 || a.tiles_x < 1 || a.tiles_y < 1 || a.mode_intensity) return false;
+    if ((NCM != 0) != (a.src.sensor != nullptr)) return false;
+    uint32_t* const visout = NCM == 1 ? a.vis2 : a.vis;
     const int R = 32;
     const size_t R2 = (R + 1) / 2;
     const size_t mask_blocks = std::max(((size_t)a.tile_cap + 63) / 64, ((size_t)a.sc.F + 63) / 64);
@@ -764,19 +766,19 @@ bool forward_tiled_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t str
     const size_t cap = (kGridLdsBudget - fixed) / 4;
     const size_t lds = fixed + cap * 4;
     // partial rows / visibility words of the tiles are combined with atomics: start from zero
-    if (rows_in_lds && a.rows) launch_zero_f64(a.rows, (size_t)a.src.L * a.sp.nbins, stream);
-    if (a.vis) (void)hipMemsetAsync(a.vis, 0, sizeof(uint32_t) * (size_t)a.src.L * a.vis_words * a.sc.F, stream);
+    if (NCM != 1 && rows_in_lds && a.rows) launch_zero_f64(a.rows, (size_t)a.src.L * a.sp.nbins, stream);
+    if (visout) (void)hipMemsetAsync(visout, 0, sizeof(uint32_t) * (size_t)a.src.L * a.vis_words * a.sc.F, stream);
     const size_t nwg = (size_t)a.src.L * a.tiles_x * a.tiles_y;
     (void)hipMemsetAsync(a.tile_count, 0, sizeof(int) * 2 * nwg, stream);      // subset sizes + retry flags
-    hipLaunchKernelGGL(k_tile_bin, dim3(a.src.L), dim3(512), 0, stream, a, R);
+    hipLaunchKernelGGL(k_tile_bin, dim3(a.src.L), dim3(512), 0, stream, a, R, NCM == 1 ? 1 : 0);
     // second launch for the tiles whose cell lists overflow: the whole CU's LDS for one workgroup
     const size_t lds_big = 150 * 1024;
     const size_t cap_big = (lds_big - fixed) / 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, 0, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, 0, true>), dim3((unsigned)nwg), dim3(512), lds, stream, a, rows_in_lds, R,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, true>), dim3((unsigned)nwg), dim3(512), lds, stream, a, rows_in_lds, R,
                        (int)cap - 1, 0);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, 0, true>), dim3((unsigned)nwg), dim3(512), lds_big, stream, a, rows_in_lds,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, true>), dim3((unsigned)nwg), dim3(512), lds_big, stream, a, rows_in_lds,
                        R, (int)cap_big - 1, 1);
     return true;
 }
@@ -790,6 +792,8 @@ bool grid_dispatch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
             if (a.vis2 && !a.mode_intensity) {
                 ForwardArgs p1 = a;
                 p1.rows = nullptr;
+                if (a.tile_list)     // large mesh: both passes through the tiled grid
+                    return forward_tiled_launch<FEAT, 1>(p1, 0, stream) && forward_tiled_launch<FEAT, 2>(a, rows_in_lds, stream);
                 return forward_grid_launch<FEAT, 1>(p1, 0, stream) && forward_grid_launch<FEAT, 2>(a, rows_in_lds, stream);
             }
         }

@@ -463,7 +463,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         if (rc) return rc;
         fa.live = c->live.as<uint16_t>();
         fa.retry = c->tile_count.as<int>();
-    } else if (a->force_bvh != 1 && !a->sensor && mode != NLOS_MODE_INTENSITY && L > 0) {
+    } else if (a->force_bvh != 1 && mode != NLOS_MODE_INTENSITY && L > 0) {
         // tiled grid: ~3000 triangles per slope-space tile on average (small tiles leave the 512 threads idle); the densest tiles of a closed surface
         // (front + back side, several depth layers) hold up to ~4.5x the mean, and the subset capacity is bounded by
         // the 14-bit entry index (overflowing tiles fall back to the BVH query by themselves);
@@ -495,7 +495,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
 #endif
     fa.rows = nullptr;
     fa.vis2 = nullptr;
-    if (a->sensor && fa.live && !fa.tile_list) {
+    if (a->sensor && fa.live) {
         // sensor-leg visibility bits of the two-pass grid path for non-confocal pairs
         rc = c->vis2.ensure(sizeof(uint32_t) * (size_t)(L > 0 ? L : 1) * vis_words * nF + 16);
         if (rc) return rc;

@@ -621,6 +621,16 @@ def test_tiled_grid_for_large_meshes_agrees_with_bvh_and_oracle(bunny, orc):
     _, g1, _ = r.render_gradient(to, tn, tv, tf_, ns, LB, UB, RES, data=data, weight=w)
     _, g2, _ = r.render_gradient(to, tn, tv, tf_, ns, LB, UB, RES, data=data, weight=w, force_bvh=True)
     assert rel_l2(g1.cpu().numpy(), g2.cpu().numpy()) <= 1e-6
+    # non-confocal pairs on the same mesh: both grid passes are tiled, too
+    tb = to.clone()
+    tb[:, 0] += 0.07
+    tb[:, 1] -= 0.05
+    tb[:, 2] = 0.0
+    ta = to.clone()
+    ta[:, 2] = 0.0
+    n1, _ = r.render_transient(ta, tn, tv, tf_, ns, LB, UB, RES, sensor=tb, sensor_normal=tn)
+    n2, _ = r.render_transient(ta, tn, tv, tf_, ns, LB, UB, RES, sensor=tb, sensor_normal=tn, force_bvh=True)
+    assert n2.sum().item() > 0 and (n1 - n2).abs().max().item() <= 1e-13 * n2.max().item()
     # V = 9.8 k: the 3V-double accumulator does not fit LDS -> face-major gradient kernel; against the oracle
     d3 = data[:3].cpu().numpy()
     _, g_ref, _ = orc.render_gradient(o[:3], n[:3], v2, f2, ns, LB, UB, RES, d3, np.ones_like(d3), accel=1, seed=4)
