@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NLOS_GRAD_NT, NLOS_GRAD_WPS) void k_gradient(Gradie
 // Same per-sample arithmetic as k_gradient<FEAT, 0>; only the fp64 summation order differs.
 constexpr int kFmChunk = 512, kFmBatch = 4, kFmThreads = 256;
 
-template <int FEAT>
+template <int FEAT, bool NC = false>
 __global__ __launch_bounds__(kFmThreads) void k_gradient_fm(GradientArgs a, int src_per_group) {
     extern __shared__ double s_fm[];      // [acc 9*CHUNK][rows BATCH*T][delta K][p0 K+1][p1 K+1][list BATCH*CHUNK u16][ctl]
     const int T = a.sp.nbins, K = a.K, F = a.sc.F;
@@ -329,19 +329,37 @@ __global__ __launch_bounds__(kFmThreads) void k_gradient_fm(GradientArgs a, int 
                 while (word) {
                     const int bit = __ffs(word) - 1;
                     word &= word - 1;
-                    Geo g;
-                    float t_self;
-                    if (!sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)((wi << 5) + bit), a.sp.lb, a.sp.ub,
-                                          a.sc.vertex_normal, a.sc.albedo, g, t_self))
-                        continue;
-                    GVec gv;
-                    grad_vectors<FEAT>(f, g, on, a.normal_term, a.v1_style, a.sp.ggx_alpha, gv);
                     const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
+                    GVec gv;
+                    V3 di;
+                    float bw[3];
+                    double twoh;
+                    if (NC) {
+                        // row N: two legs, d(d1 + d2)/dp = dirA + dirB; P1 carries the confocal factor 2
+                        GeoNC gc;
+                        float tA, tB;
+                        if (!sample_geo_nc<FEAT>(f, tr, o, ld3(a.src.sensor + 3 * (size_t)l), a.sp.seed,
+                                                 kbase + (uint64_t)((wi << 5) + bit), a.sp.lb, a.sp.ub, a.sc.vertex_normal,
+                                                 a.sc.albedo, gc, tA, tB))
+                            continue;
+                        grad_vectors_nc<FEAT>(f, gc, on, ld3(a.src.sensor_normal + 3 * (size_t)l), a.normal_term, gv);
+                        di = ((gc.dirA + gc.dirB) * 0.5f) * gv.inten_f;
+                        bw[0] = gc.u; bw[1] = gc.v; bw[2] = gc.w;
+                        twoh = (double)(gc.d1 + gc.d2);
+                    } else {
+                        Geo g;
+                        float t_self;
+                        if (!sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)((wi << 5) + bit), a.sp.lb, a.sp.ub,
+                                              a.sc.vertex_normal, a.sc.albedo, g, t_self))
+                            continue;
+                        grad_vectors<FEAT>(f, g, on, a.normal_term, a.v1_style, a.sp.ggx_alpha, gv);
+                        di = g.dir * gv.inten_f;
+                        bw[0] = g.u; bw[1] = g.v; bw[2] = g.w;
+                        twoh = (double)(2.0f * g.h);
+                    }
                     const V3 ce[3] = {cross(gv.t2, e0), cross(gv.t2, e1), cross(gv.t2, e2)};
                     double s0, s1;
-                    grouped_taps(tt, s_diff, T, (double)(2.0f * g.h), lbd, resd, inv_res, s0, s1);
-                    const V3 di = g.dir * gv.inten_f;
-                    const float bw[3] = {g.u, g.v, g.w};
+                    grouped_taps(tt, s_diff, T, twoh, lbd, resd, inv_res, s0, s1);
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         const V3 A1 = gv.t1 * bw[q] + ce[q];
@@ -376,7 +394,8 @@ __global__ __launch_bounds__(kFmThreads) void k_gradient_fm(GradientArgs a, int 
 template <int FEAT>
 bool gradient_fm_launch(const GradientArgs& a, hipStream_t stream) {
     // only the plain vertex gradient of meshes whose 3V accumulator cannot live in LDS
-    if (a.mode != 0 || a.src.sensor || a.sp.nbins * kFmBatch > 8192) return false;
+    if (a.mode != 0 || a.sp.nbins * kFmBatch > 8192) return false;
+    if (a.src.sensor && (FEAT & FEAT_GGX)) return false;
     const size_t lds = ((size_t)9 * kFmChunk + (size_t)kFmBatch * a.sp.nbins + 3 * (size_t)a.K + 2) * sizeof(double) +
                        (size_t)kFmBatch * kFmChunk * 2 + 16;
     if (lds > 80 * 1024) return false;
@@ -387,6 +406,14 @@ bool gradient_fm_launch(const GradientArgs& a, hipStream_t stream) {
     per = ((per + kFmBatch - 1) / kFmBatch) * kFmBatch;
     if (per < kFmBatch) per = kFmBatch;
     groups = (a.src.L + per - 1) / per;
+    if (a.src.sensor) {
+        if constexpr ((FEAT & FEAT_GGX) == 0) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient_fm<FEAT, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient_fm<FEAT, true>), dim3(nchunks, groups), dim3(kFmThreads), lds, stream, a, per);
+        }
+        return true;
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient_fm<FEAT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient_fm<FEAT>), dim3(nchunks, groups), dim3(kFmThreads), lds, stream, a, per);
@@ -434,7 +461,7 @@ void launch_gradient(const GradientArgs& a_in, hipStream_t stream) {
     // per-workgroup 3V-double accumulator while it fits beside the rest (one workgroup per CU at worst)
     const size_t acc = 3 * (size_t)a.sc.V * sizeof(double);
     a.lds_grad = ((a.mode == 0 || a.mode == 4) && a_in.lds_grad && lds + acc <= 150 * 1024) ? 1 : 0;
-    if (!a.lds_grad && a.mode == 0 && !a.src.sensor && a_in.lds_grad) {
+    if (!a.lds_grad && a.mode == 0 && a_in.lds_grad) {
         // large meshes: face-major variant (per-face sums in LDS across sources, one scatter per face)
         bool done = false;
         switch (feat_of(a.sc, a.sp)) {

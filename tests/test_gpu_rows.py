@@ -631,6 +631,13 @@ def test_tiled_grid_for_large_meshes_agrees_with_bvh_and_oracle(bunny, orc):
     n1, _ = r.render_transient(ta, tn, tv, tf_, ns, LB, UB, RES, sensor=tb, sensor_normal=tn)
     n2, _ = r.render_transient(ta, tn, tv, tf_, ns, LB, UB, RES, sensor=tb, sensor_normal=tn, force_bvh=True)
     assert n2.sum().item() > 0 and (n1 - n2).abs().max().item() <= 1e-13 * n2.max().item()
+    a3, b3 = ta[:3].contiguous(), tb[:3].contiguous()
+    dn = (n1[:3] * 1.2).contiguous()
+    _, gn_ref, _ = orc.render_nonconfocal(a3.cpu().numpy(), n[:3], b3.cpu().numpy(), n[:3], v2, f2, ns, LB, UB, RES,
+                                          data=dn.cpu().numpy(), weight=np.ones((3, T)), accel=1, seed=4)
+    _, gn, _ = r.render_gradient(a3, tn[:3].contiguous(), tv, tf_, ns, LB, UB, RES, data=dn, weight=torch.ones_like(dn),
+                                 sensor=b3, sensor_normal=tn[:3].contiguous())
+    assert np.abs(gn_ref).max() > 0 and rel_l2(gn.cpu().numpy(), gn_ref) <= 1e-4      # face-major kernel, NC variant
     # V = 9.8 k: the 3V-double accumulator does not fit LDS -> face-major gradient kernel; against the oracle
     d3 = data[:3].cpu().numpy()
     _, g_ref, _ = orc.render_gradient(o[:3], n[:3], v2, f2, ns, LB, UB, RES, d3, np.ones_like(d3), accel=1, seed=4)
