@@ -143,3 +143,17 @@ def test_facade_signatures_exist():
     assert list(inspect.signature(rendering.space_carving_projection).parameters) == ["v", "space_carving_mesh"]
     w = rendering.create_weighting_function(np.array([[1.0, 2.0], [3.0, 4.0]]), 0)
     assert np.allclose(w, 1.0)
+
+
+def test_public_headers_are_plain_c(tmp_path):
+    """The drop-in boundary must be bindable from C / cgo / JNI / ctypes: include/nlos_hip.h (and the
+    oracle's header) compile as strict C99, no C++ or HIP types in the signatures."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no gcc")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "%s"\n#include "%s"\nint main(void) { nlos_render_args a; (void)a; return nlos_sizeof_render_args() > 0 ? 0 : 1; }\n'
+                   % (os.path.join(ROOT, "include", "nlos_hip.h"), os.path.join(ROOT, "oracle", "nlos_oracle.h")))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", str(src), "-o", str(tmp_path / "hdr.o")])
