@@ -134,14 +134,39 @@ def main():
                 t, _ = r.render_transient(to, tn, tv, tf_, ns, lb, ub, res, sensor=tb, sensor_normal=tn, force_bvh=fb)
                 en = max(en, rel_l2(t.cpu().numpy(), tn_ref))
             et = max(et, en)
+        ex = 0.0
+        if rs.rand() < 0.3 and t_ref.sum() > 0 and F <= 5800:
+            # other rows on the same scene: GGX branch, SPAD jitter gradient, v1 driver, per-face intensity
+            alpha = float(rs.uniform(0.05, 0.9))
+            tg_ref, _ = orc.render_transient(o, nrm, v, f, ns, lb, ub, res, ggx_alpha=alpha, vnormal=vn, accel=1, seed=case)
+            tg, _ = r.render_transient(to, tn, tv, tf_, ns, lb, ub, res, alpha=alpha, vertex_normal=tvn)
+            ex = max(ex, rel_l2(tg.cpu().numpy(), tg_ref) if tg_ref.sum() > 0 else 0.0)
+            jk = np.load(os.path.join(ROOT, "tests", "golden", "jitter_info.npz"))
+            jw, jg, jo = jk["jitter_weight"], jk["jitter_grad"], int(jk["jitter_offset"])
+            tj_ref, _, _ = orc.render_jitter(o, nrm, v, f, ns, lb, ub, res, jw, jo, accel=1, seed=case)
+            dj = tj_ref * 1.25
+            _, gj_ref, _ = orc.render_jitter(o, nrm, v, f, ns, lb, ub, res, jw, jo, jitter_grad=jg, data=dj,
+                                             weight=np.ones_like(dj), testing_flag=1, accel=1, seed=case)
+            tjw = torch.from_numpy(np.ascontiguousarray(jw.ravel())).to(dev)
+            tjg = torch.from_numpy(np.ascontiguousarray(jg.ravel())).to(dev)
+            tj, gj, _ = r.render_gradient(to, tn, tv, tf_, ns, lb, ub, res, data=torch.from_numpy(dj).to(dev),
+                                          weight=torch.ones(dj.shape, dtype=torch.float64, device=dev),
+                                          jitter_weight=tjw, jitter_grad=tjg, jitter_offset=jo, testing_flag=1)
+            ex = max(ex, rel_l2(tj.cpu().numpy(), tj_ref))
+            if np.abs(gj_ref).max() > 0:
+                eg = max(eg, rel_l2(gj.cpu().numpy(), gj_ref))
+            it_ref = orc.render_intensity(o, nrm, v, f, ns, lb, ub, accel=1, seed=case)
+            it = r.render_intensity(to, tn, tv, tf_, ns, lb, ub)
+            ex = max(ex, rel_l2(it.cpu().numpy(), it_ref) if it_ref.sum() > 0 else 0.0)
+            et = max(et, ex)
         r.close()
         ok = et <= 1e-5 and eg <= 1e-4          # 1e-5: a grazing-occluder sample or two
         grazing += int(et > 1e-12)
         if not ok and t_ref.sum() > 0:
             bad += 1
         worst_t, worst_g = max(worst_t, et), max(worst_g, eg)
-        print("case %3d F=%6d L=%d spt=%2d T=%4d vn=%d sum=%.3e  transient %.2e (grid/bvh%s)  gradient %.2e  nc %.2e %s" % (
-            case, F, L, spt, T, int(use_vn), t_ref.sum(), et, "/ovf" if F > 5800 else "", eg, en, "" if ok else "  <-- MISMATCH"),
+        print("case %3d F=%6d L=%d spt=%2d T=%4d vn=%d sum=%.3e  transient %.2e (grid/bvh%s)  gradient %.2e  nc %.2e  ggx/jitter/intensity %.2e %s" % (
+            case, F, L, spt, T, int(use_vn), t_ref.sum(), et, "/ovf" if F > 5800 else "", eg, en, ex, "" if ok else "  <-- MISMATCH"),
             flush=True)
     print("cases with a differing sample (grazing-occluder candidates, see tools/fuzz_case.py): %d" % grazing)
     print("worst transient %.3e, worst gradient %.3e, mismatches %d / %d" % (worst_t, worst_g, bad, n_cases))
