@@ -105,7 +105,7 @@ __global__ __launch_bounds__(NLOS_GRAD_NT, NLOS_GRAD_WPS) void k_gradient(Gradie
             const uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
             const Face f = load_face(a.sc.facerec, j);
             if (MODE == 3 && f.i0 != a.vertex_num && f.i1 != a.vertex_num && f.i2 != a.vertex_num) continue;
-            const Tri tr = load_tri(a.sc.tris, j);
+            const Tri tr = make_tri(f.p0, f.p1, f.p2);      // what the builder stored (same function, same bits): no 48-B gather
             const uint64_t kbase = (lg * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
             double acc[9];
 #pragma unroll
