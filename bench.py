@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--subdivide", type=int, default=0,
                     help="side measurement (not the metric): 1->4 midpoint subdivision passes of the mesh (F x 4^n)")
+    ap.add_argument("--mesh", choices=["bunny_5k", "mannequin"], default="bunny_5k",
+                    help="side measurement: exp_mannequin/cnlos_mannequin_threshold.obj (1055 faces) instead of the metric's bunny")
     ap.add_argument("--faces", type=int, default=0,
                     help="side measurement: subdivide once, then vertex-cluster down to about this many faces")
     ap.add_argument("--non-confocal", action="store_true",
@@ -131,7 +133,7 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
-    d = np.load(os.path.join(ROOT, "tests", "golden", "bunny_5k.npz"))
+    d = np.load(os.path.join(ROOT, "tests", "golden", args.mesh + ".npz"))
     v_np = np.ascontiguousarray(d["v"], np.float32)
     f_np = np.ascontiguousarray(d["f"], np.int32)
     if args.subdivide > 0:
@@ -225,8 +227,8 @@ def main():
                 "workload": ("NON-CONFOCAL pairs (row N side measurement, not the metric) " if args.non_confocal else "") +
                             ("SUBDIVIDED mesh x4^%d (side measurement, not the metric) " % args.subdivide if args.subdivide else "") +
                             ("forward-only " if args.forward_only else "forward+gradient ") +
-                            "%dx%d confocal sources per GPU x %d bins, bunny_5k (F=%d, V=%d), num_sample=%d "
-                            "(spt=%d), refine=10, sigma_bin=1, BVH rebuilt every step" % (g, g, T, F, V, args.num_sample, spt),
+                            "%dx%d confocal sources per GPU x %d bins, %s (F=%d, V=%d), num_sample=%d "
+                            "(spt=%d), refine=10, sigma_bin=1, BVH rebuilt every step" % (g, g, T, args.mesh, F, V, args.num_sample, spt),
                 "sources_total": L_total, "faces": F, "bins": T, "spt": spt,
                 "parallelism": "source-block sharding x%d + one all-reduce of the 3V gradient" % world,
             },
@@ -240,14 +242,14 @@ def main():
             achieved = per_sample * local_samples / (kt[dom] * 1e-3) / 1e9
             pmc = load_pmc_traffic()
             traffic = None
-            if pmc and not args.non_confocal and not args.subdivide and not args.faces and pmc.get("kernel") == names[dom] and pmc.get("L") == L and pmc.get("F") == F:
+            if pmc and not args.non_confocal and not args.subdivide and not args.faces and args.mesh == "bunny_5k" and pmc.get("kernel") == names[dom] and pmc.get("L") == L and pmc.get("F") == F:
                 traffic = pmc.get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_sample": per_sample,
                                "kernel_ms": {n: float(x) for n, x in zip(names, kt)},
                                "step_algorithmic_GBps": (200.0 + 72.0 / spt) * local_samples / (ms * 1e-3) / 1e9}
-        if world == 1 and not args.no_cpu_baseline and not args.forward_only and not args.non_confocal and not args.subdivide and not args.faces:
+        if world == 1 and not args.no_cpu_baseline and not args.forward_only and not args.non_confocal and not args.subdivide and not args.faces and args.mesh == "bunny_5k":
             out["cpu_baseline"] = cpu_baseline(v_np, f_np, origin_np, normal_np, lb, ub, res, args.num_sample,
                                                data.cpu().numpy())
         print(json.dumps(out))
