@@ -94,7 +94,21 @@ def cpu_baseline(v, f, origin, normal, lb, ub, res, num_sample, data_rows, budge
                       "buffers" % (n, L, t, cores, avail)}
 
 
-def main():
+def workload_config(args, g, T, F, V, spt, L_total, world):
+    """The `config` object of the JSON line (names the workload; the side-measurement flags say so)."""
+    return {
+        "workload": ("NON-CONFOCAL pairs (row N side measurement, not the metric) " if args.non_confocal else "") +
+                    ("SUBDIVIDED mesh x4^%d (side measurement, not the metric) " % args.subdivide if args.subdivide else "") +
+                    ("RE-DECIMATED mesh (side measurement, not the metric) " if args.faces else "") +
+                    ("forward-only " if args.forward_only else "forward+gradient ") +
+                    "%dx%d confocal sources per GPU x %d bins, %s (F=%d, V=%d), num_sample=%d "
+                    "(spt=%d), refine=10, sigma_bin=1, BVH rebuilt every step" % (g, g, T, args.mesh, F, V, args.num_sample, spt),
+        "sources_total": L_total, "faces": F, "bins": T, "spt": spt,
+        "parallelism": "source-block sharding x%d + one all-reduce of the 3V gradient" % world,
+    }
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -114,7 +128,11 @@ def main():
     ap.add_argument("--non-confocal", action="store_true",
                     help="row N side measurement (not the metric): every source becomes a (laser, sensor) pair, "
                          "sensor = laser + (0.05, -0.03, 0)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
 
     import torch
     import torch.distributed as dist
@@ -223,15 +241,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 per-sample math, f64 accumulation",
             "data": "synthetic",
-            "config": {
-                "workload": ("NON-CONFOCAL pairs (row N side measurement, not the metric) " if args.non_confocal else "") +
-                            ("SUBDIVIDED mesh x4^%d (side measurement, not the metric) " % args.subdivide if args.subdivide else "") +
-                            ("forward-only " if args.forward_only else "forward+gradient ") +
-                            "%dx%d confocal sources per GPU x %d bins, %s (F=%d, V=%d), num_sample=%d "
-                            "(spt=%d), refine=10, sigma_bin=1, BVH rebuilt every step" % (g, g, T, args.mesh, F, V, args.num_sample, spt),
-                "sources_total": L_total, "faces": F, "bins": T, "spt": spt,
-                "parallelism": "source-block sharding x%d + one all-reduce of the 3V gradient" % world,
-            },
+            "config": workload_config(args, g, T, F, V, spt, L_total, world),
         }
         # roofline of the dominant kernel, measured live (HIP events, rank 0, this rank's launches)
         names = ["bvh_build", "k_forward", "k_residual", "k_gradient"]

@@ -157,3 +157,20 @@ def test_public_headers_are_plain_c(tmp_path):
     src.write_text('#include "%s"\n#include "%s"\nint main(void) { nlos_render_args a; (void)a; return nlos_sizeof_render_args() > 0 ? 0 : 1; }\n'
                    % (os.path.join(ROOT, "include", "nlos_hip.h"), os.path.join(ROOT, "oracle", "nlos_oracle.h")))
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", str(src), "-o", str(tmp_path / "hdr.o")])
+
+
+def test_bench_contract_helpers_run_without_a_gpu():
+    """bench.py's argument parsing and the `config` object of its JSON line (CPU-only parts)."""
+    import json
+    import bench
+    a = bench.parse_args([])
+    assert a.gpus == 1 and a.steps >= 1 and a.warmup >= 0 and a.bins == 512 and a.num_sample == 20000
+    c = bench.workload_config(a, 64, 512, 4967, 2432, 5, 4096, 1)
+    assert "64x64 confocal sources" in c["workload"] and "bunny_5k" in c["workload"] and "model" not in c
+    json.dumps(c)
+    for flags in (["--non-confocal"], ["--subdivide", "1"], ["--faces", "6000"], ["--mesh", "mannequin", "--bins", "1024"],
+                  ["--forward-only"]):
+        b = bench.parse_args(flags)
+        w = bench.workload_config(b, 32, b.bins, 1000, 500, 4, 1024, 1)["workload"]
+        assert ("side measurement" in w) == (flags[0] in ("--non-confocal", "--subdivide", "--faces"))
+    assert bench.METRIC.startswith("surface samples/sec fwd+grad")
