@@ -18,23 +18,21 @@ from . import _lib
 
 class Adam_Modified(Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
-        # adam_modified.py:33-40
-        if not 0.0 <= lr:
-            raise ValueError("Invalid learning rate: {}".format(lr))
-        if not 0.0 <= eps:
-            raise ValueError("Invalid epsilon value: {}".format(eps))
-        if not 0.0 <= betas[0] < 1.0:
-            raise ValueError("Invalid beta parameter at index 0: {}".format(betas[0]))
-        if not 0.0 <= betas[1] < 1.0:
-            raise ValueError("Invalid beta parameter at index 1: {}".format(betas[1]))
-        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
-        super().__init__(params, defaults)
-        self._ctx = {}
+        # same argument checks and messages as the reference class (exp_bunny/adam_modified.py:33-40)
+        b1, b2 = betas
+        for bad, what, val in ((lr < 0.0, "learning rate", lr), (eps < 0.0, "epsilon value", eps),
+                               (not 0.0 <= b1 < 1.0, "beta parameter at index 0", b1),
+                               (not 0.0 <= b2 < 1.0, "beta parameter at index 1", b2)):
+            if bad:
+                raise ValueError("Invalid %s: %s" % (what, val))
+        super().__init__(params, {"lr": lr, "betas": (b1, b2), "eps": eps, "weight_decay": weight_decay,
+                                  "amsgrad": amsgrad})
+        self._ctx = {}          # one render context (scratch owner) per device
 
     def __setstate__(self, state):
         super().__setstate__(state)
-        for group in self.param_groups:
-            group.setdefault('amsgrad', False)
+        for g in self.param_groups:
+            g.setdefault("amsgrad", False)
 
     def _handle(self, device):
         h = self._ctx.get(device.index)
@@ -81,10 +79,8 @@ class Adam_Modified(Optimizer):
                 if grad.dtype not in (torch.float32, torch.float64):
                     raise ValueError("Adam_Modified: grad must be float32 or float64")
                 state = self.state[p]
-                if len(state) == 0:
-                    state['step'] = 0
-                    state['exp_avg'] = torch.zeros_like(p.data)
-                    state['exp_avg_sq'] = torch.zeros_like(p.data)
+                if not state:
+                    state.update(step=0, exp_avg=torch.zeros_like(p.data), exp_avg_sq=torch.zeros_like(p.data))
                     if group['amsgrad']:
                         state['max_exp_avg_sq'] = torch.zeros_like(p.data)
                 state['step'] += 1
