@@ -644,3 +644,36 @@ def test_tiled_grid_for_large_meshes_agrees_with_bvh_and_oracle(bunny, orc):
     _, g3, _ = r.render_gradient(to[:3].contiguous(), tn[:3].contiguous(), tv, tf_, ns, LB, UB, RES,
                                  data=data[:3].contiguous(), weight=w[:3].contiguous())
     assert np.abs(g_ref).max() > 0 and rel_l2(g3.cpu().numpy(), g_ref) <= 1e-4
+
+
+def test_render_step_is_hip_graph_capturable(bunny):
+    """After one warm-up call (scratch allocated, tap tables uploaded) a whole forward + gradient render is a
+    fixed sequence of launches on the caller's stream: it can be captured into a HIP graph and replayed."""
+    import torch
+    from nlos_surface_optimization_amd import device as nd
+    v, f = bunny
+    o, n = grid_sources(4, 0.25)
+    dev = torch.device("cuda", 0)
+    r = nd.TransientRenderer(dev, seed=1)
+    tv, tf_, to, tn = (torch.from_numpy(x).to(dev) for x in (v, f, o, n))
+    data = torch.zeros((16, T), dtype=torch.float64, device=dev)
+    w = torch.ones_like(data)
+    grad = torch.zeros((v.shape[0], 3), dtype=torch.float64, device=dev)
+    t_ref, g_ref, _ = r.render_gradient(to, tn, tv, tf_, 20000, LB, UB, RES, data=data, weight=w)     # warm-up + reference
+    s = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(s):
+        out = {}
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            grad.zero_()
+            out["t"], _, _ = r.render_gradient(to, tn, tv, tf_, 20000, LB, UB, RES, data=data, weight=w, gradient=grad)
+        # move the mesh, replay: the graph re-reads the vertex buffer
+        tv.add_(0.001)
+        g.replay()
+        torch.cuda.synchronize()
+    t2, g2, _ = r.render_gradient(to, tn, tv, tf_, 20000, LB, UB, RES, data=data, weight=w)
+    assert (out["t"] - t2).abs().max().item() <= 1e-13 * t2.max().item()
+    assert rel_l2(grad.cpu().numpy(), g2.cpu().numpy()) <= 1e-9
+    assert (t2 - t_ref).abs().max().item() > 0          # the replay really rendered the moved mesh
