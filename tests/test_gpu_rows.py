@@ -309,8 +309,9 @@ def test_grid_kernel_in_kernel_fallbacks_vs_oracle(bunny, orc):
     assert rel_l2(grad, g_o) <= 1e-4
 
 
-def test_large_mesh_uses_bvh_path_vs_oracle(orc):
-    """F beyond the grid kernel's LDS budget (here the bunny decimated to ~12k faces): packet BVH path."""
+def test_large_mesh_vs_oracle(orc):
+    """F beyond one workgroup's LDS budget (the bunny refined to ~12k faces, partly subdivided -> mixed
+    triangle sizes): tiled grid by default, packet BVH with force_bvh."""
     from nlos_surface_optimization_amd import mesh_io, renderer
     d = np.load(os.path.join(GOLDEN, "bunny_5k.npz"))
     # refine the 5k bunny by 1->4 midpoint subdivision of a subset: ~12k faces, all inside the same surface
@@ -334,6 +335,13 @@ def test_large_mesh_uses_bvh_path_vs_oracle(orc):
     renderer.renderStreamedTransient(origin, normal, v2, f2, 30000, LB, UB, RES, tr, path, 1, 1)
     t_o, _ = orc.render_transient(origin, normal, v2, f2, 30000, LB, UB, RES, accel=1)
     assert rel_l2(tr, t_o) <= 1e-5 and tr.sum() > 0
+    import torch
+    from nlos_surface_optimization_amd import device as nd
+    dev = torch.device("cuda", 0)
+    r = nd.TransientRenderer(dev, seed=0)
+    tb, _ = r.render_transient(torch.from_numpy(origin).to(dev), torch.from_numpy(normal).to(dev), torch.from_numpy(v2).to(dev),
+                               torch.from_numpy(f2).to(dev), 30000, LB, UB, RES, force_bvh=True)
+    assert rel_l2(tb.cpu().numpy(), t_o) <= 1e-12
 
 
 # ------------------------------------------------------------------ row N: non-confocal pairs
