@@ -752,7 +752,7 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
 // meshes beyond one workgroup's LDS: one workgroup per (source, slope-space tile)
 template <int FEAT, int NCM = 0>
 bool forward_tiled_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
-    if (a.force_bvh || !a.tile_list || !a.tile_count || !a.live || a.tiles_x * a.tiles_y > 1024 || a.tiles_x < 1 || a.tiles_y < 1 || a.mode_intensity) return false;
+    if (a.force_bvh || !a.tile_list || !a.tile_count || !a.live || a.tiles_x * a.tiles_y > 1024 || a.tiles_x < 1 || a.tiles_y < 1) return false;
     if ((NCM != 0) != (a.src.sensor != nullptr)) return false;
     uint32_t* const visout = NCM == 1 ? a.vis2 : a.vis;
     const int R = 32;

@@ -463,7 +463,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         if (rc) return rc;
         fa.live = c->live.as<uint16_t>();
         fa.retry = c->tile_count.as<int>();
-    } else if (a->force_bvh != 1 && mode != NLOS_MODE_INTENSITY && L > 0) {
+    } else if (a->force_bvh != 1 && L > 0) {
         // tiled grid: ~3000 triangles per slope-space tile on average (small tiles leave the 512 threads idle); the densest tiles of a closed surface
         // (front + back side, several depth layers) hold up to ~4.5x the mean, and the subset capacity is bounded by
         // the 14-bit entry index (overflowing tiles fall back to the BVH query by themselves);

@@ -629,6 +629,10 @@ def test_tiled_grid_for_large_meshes_agrees_with_bvh_and_oracle(bunny, orc):
     _, g1, _ = r.render_gradient(to, tn, tv, tf_, ns, LB, UB, RES, data=data, weight=w)
     _, g2, _ = r.render_gradient(to, tn, tv, tf_, ns, LB, UB, RES, data=data, weight=w, force_bvh=True)
     assert rel_l2(g1.cpu().numpy(), g2.cpu().numpy()) <= 1e-6
+    # per-face intensity (row X) through the tiled grid
+    it_ref = orc.render_intensity(o[:3], n[:3], v2, f2, ns, 0.0, 2.0, accel=1, seed=4)
+    it = r.render_intensity(to[:3].contiguous(), tn[:3].contiguous(), tv, tf_, ns, 0.0, 2.0)
+    assert it_ref.sum() > 0 and rel_l2(it.cpu().numpy(), it_ref) <= 1e-12
     # non-confocal pairs on the same mesh: both grid passes are tiled, too
     tb = to.clone()
     tb[:, 0] += 0.07
