@@ -6,9 +6,8 @@
 //   k_forward_nc  <- row N (non-confocal pairs), two shadow legs per sample
 // One workgroup per source, histogram row in LDS, one lane per face (Morton order) looping over the
 // face's strata; the CH rays of a (source, face) chunk traverse the BVH together as a packet.  This is
-// the back-end for tiny meshes (F < 64), rows beyond LDS, the intensity mode of large meshes,
-// `force_bvh`, and non-confocal pairs on meshes the grid cannot hold; the grid kernels
-// (forward_grid.hip) are the fast path.
+// the back-end for tiny meshes (F < 64) and `force_bvh`; the grid kernels (forward_grid.hip) are the
+// fast path and cover everything else.
 #include "render_common.h"
 
 namespace nlos {
