@@ -755,7 +755,10 @@ bool forward_tiled_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t str
     if (a.force_bvh || !a.tile_list || !a.tile_count || !a.live || a.tiles_x * a.tiles_y > 1024 || a.tiles_x < 1 || a.tiles_y < 1) return false;
     if ((NCM != 0) != (a.src.sensor != nullptr)) return false;
     uint32_t* const visout = NCM == 1 ? a.vis2 : a.vis;
-    const int R = 32;
+#ifndef NLOS_TILE_R
+#define NLOS_TILE_R 32
+#endif
+    const int R = NLOS_TILE_R;
     const size_t R2 = (R + 1) / 2;
     const size_t mask_blocks = std::max(((size_t)a.tile_cap + 63) / 64, ((size_t)a.sc.F + 63) / 64);
     size_t union_words = ((R2 * R2 + 1) & ~(size_t)1) + 2 * mask_blocks;
