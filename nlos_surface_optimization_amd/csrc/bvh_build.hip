@@ -21,6 +21,8 @@
 #include "nlos_device.h"
 #include "nlos_kernels.h"
 
+#include <algorithm>
+
 namespace nlos {
 
 namespace {
@@ -134,6 +136,134 @@ __device__ __forceinline__ void leaf_records(const BuildArgs& a, const int* __re
 }
 
 }  // namespace
+
+// ---- chip-wide front end for large meshes: bounds, Morton keys, LSD radix sort (8-bit digits) -----------
+// The single-workgroup builder needs 2 ms for its first three phases at F = 79 k; these kernels do the same
+// work with every CU (same keys, same stable order, hence the same tree).
+constexpr int ST = 256;            // threads per sort block
+constexpr int SKEYS = 8;           // keys per thread
+constexpr int STILE = ST * SKEYS;  // keys per block
+
+__global__ __launch_bounds__(256) void k_build_bounds(BuildArgs a, uint32_t* bkeys /* [6]: min keys 0..2, max keys 3..5 */) {
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < a.F; f += gridDim.x * blockDim.x) {
+        for (int k = 0; k < 3; ++k) {
+            int vi = clamp_index(a.faces[3 * f + k], a.V, a.status);
+            for (int c = 0; c < 3; ++c) {
+                float x = a.vertices[3 * (size_t)vi + c];
+                lo[c] = fminf(lo[c], x);
+                hi[c] = fmaxf(hi[c], x);
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = fminf(lo[c], __shfl_down(lo[c], off));
+            hi[c] = fmaxf(hi[c], __shfl_down(hi[c], off));
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int c = 0; c < 3; ++c) {
+            atomicMin(&bkeys[c], fkey(lo[c]));
+            atomicMax(&bkeys[3 + c], fkey(hi[c]));
+        }
+}
+
+__global__ __launch_bounds__(256) void k_build_morton(BuildArgs a, const uint32_t* bkeys) {
+    float lo[3], hi[3];
+    float e = 0.0f;
+    for (int c = 0; c < 3; ++c) {
+        lo[c] = fkey_inv(bkeys[c]);
+        hi[c] = fkey_inv(bkeys[3 + c]);
+        e = fmaxf(e, fmaxf(fabsf(lo[c]), fabsf(hi[c])));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.box[6 * (size_t)(2 * a.F - 1)] = 1e-4f * e + 1e-30f;   // box padding
+    const float sx = hi[0] - lo[0], sy = hi[1] - lo[1], sz = hi[2] - lo[2];
+    const float ix = sx > 0 ? 1.0f / sx : 0.0f, iy = sy > 0 ? 1.0f / sy : 0.0f, iz = sz > 0 ? 1.0f / sz : 0.0f;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.F) return;
+    float c[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) {
+        int vi = clamp_index(a.faces[3 * f + k], a.V, a.status);
+        for (int q = 0; q < 3; ++q) c[q] += a.vertices[3 * (size_t)vi + q];
+    }
+    float nx = (c[0] * (1.0f / 3.0f) - lo[0]) * ix;
+    float ny = (c[1] * (1.0f / 3.0f) - lo[1]) * iy;
+    float nz = (c[2] * (1.0f / 3.0f) - lo[2]) * iz;
+    uint32_t qx = (uint32_t)fminf(fmaxf(nx * 1024.0f, 0.0f), 1023.0f);
+    uint32_t qy = (uint32_t)fminf(fmaxf(ny * 1024.0f, 0.0f), 1023.0f);
+    uint32_t qz = (uint32_t)fminf(fmaxf(nz * 1024.0f, 0.0f), 1023.0f);
+    a.keys0[f] = (expand_bits(qx) << 2) | (expand_bits(qy) << 1) | expand_bits(qz);
+    a.idx0[f] = f;
+}
+
+__global__ __launch_bounds__(ST) void k_sort_hist(const uint32_t* __restrict__ keys, int n, int shift, uint32_t* gh, int nb) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = 0; k < SKEYS; ++k) {
+        const int i = blockIdx.x * STILE + k * ST + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    gh[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];      // digit-major: the flat scan gives stable offsets
+}
+
+__global__ __launch_bounds__(1024) void k_sort_scan(uint32_t* gh, int total) {
+    __shared__ uint32_t s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (total + 1023) / 1024;
+    const int c0 = min(tid * per, total), c1 = min(c0 + per, total);
+    uint32_t sum = 0;
+    for (int i = c0; i < c1; ++i) sum += gh[i];
+    uint32_t incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += s_w[w];
+    uint32_t run = base + incl - sum;
+    for (int i = c0; i < c1; ++i) { uint32_t v = gh[i]; gh[i] = run; run += v; }
+}
+
+__global__ __launch_bounds__(ST) void k_sort_scatter(const uint32_t* __restrict__ keys_in, const int* __restrict__ idx_in,
+                                                     uint32_t* __restrict__ keys_out, int* __restrict__ idx_out, int n, int shift,
+                                                     const uint32_t* __restrict__ gh, int nb) {
+    __shared__ uint32_t cnt[256];          // next free global slot of every digit for this block
+    __shared__ uint32_t cntw[ST / 64][256]; // per wave: keys of that digit in the current round
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    cnt[tid] = gh[(size_t)tid * nb + blockIdx.x];
+    for (int w = 0; w < ST / 64; ++w) cntw[w][tid] = 0;
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int r = 0; r < SKEYS; ++r) {          // rounds in key order: the sort stays stable
+        const int i = blockIdx.x * STILE + r * ST + tid;
+        const bool valid = i < n;
+        const uint32_t key = valid ? keys_in[i] : 0u;
+        const uint32_t d = (key >> shift) & 255u;
+        unsigned long long m = __ballot(valid);
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bb = __ballot((d >> b) & 1u);
+            m &= ((d >> b) & 1u) ? bb : ~bb;
+        }
+        const int rank = __popcll(m & lt);
+        if (valid && rank == 0) cntw[wave][d] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (valid) {
+            uint32_t off = cnt[d];
+            for (int w = 0; w < wave; ++w) off += cntw[w][d];
+            keys_out[off + rank] = key;
+            idx_out[off + rank] = idx_in[i];
+        }
+        __syncthreads();
+        uint32_t add = 0;
+        for (int w = 0; w < ST / 64; ++w) { add += cntw[w][tid]; cntw[w][tid] = 0; }
+        cnt[tid] += add;
+        __syncthreads();
+    }
+}
 
 // Large meshes (inner nodes beyond the LDS refit): the single workgroup stops after the sort and two
 // chip-wide launches finish the job -- the tree (one thread per inner node) and the refit (one thread per
@@ -408,14 +538,33 @@ void launch_build_bvh(const BuildArgs& a, hipStream_t stream) {
     const size_t refit = 7 * sizeof(uint32_t) * (size_t)(a.F > 1 ? a.F - 1 : 0);
     const size_t lds_max = 160 * 1024 - 1024;
     if (refit > lds && refit <= lds_max) lds = refit;
-    const int split = (refit > lds_max && a.F > 1) ? 1 : 0;      // tree + refit as chip-wide launches
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_bvh), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    hipLaunchKernelGGL(k_build_bvh, dim3(1), dim3(BT), lds, stream, a, (int)(lds / sizeof(uint32_t)), split);
-    if (split) {
-        hipLaunchKernelGGL(k_build_tree, dim3((a.F + 255) / 256), dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(k_build_refit, dim3((a.F + 255) / 256), dim3(256), 0, stream, a);
+    const int split = (refit > lds_max && a.F > 1) ? 1 : 0;      // beyond the LDS refit: chip-wide launches
+    if (!split) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_bvh), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        hipLaunchKernelGGL(k_build_bvh, dim3(1), dim3(BT), lds, stream, a, (int)(lds / sizeof(uint32_t)), 0);
+        return;
     }
+    // bounds -> Morton keys -> 4 x (histogram, scan, scatter) -> tree -> refit
+    uint32_t* bkeys = reinterpret_cast<uint32_t*>(a.status) + 16;          // 6 order-preserving bound keys
+    (void)hipMemsetAsync(bkeys, 0xFF, 3 * sizeof(uint32_t), stream);
+    (void)hipMemsetAsync(bkeys + 3, 0x00, 3 * sizeof(uint32_t), stream);
+    const int fb = (a.F + 255) / 256;
+    hipLaunchKernelGGL(k_build_bounds, dim3(std::min(fb, 1024)), dim3(256), 0, stream, a, bkeys);
+    hipLaunchKernelGGL(k_build_morton, dim3(fb), dim3(256), 0, stream, a, bkeys);
+    const int nb = (a.F + STILE - 1) / STILE;
+    uint32_t* gh = reinterpret_cast<uint32_t*>(a.child);                   // 256 * nb words, free until k_build_tree
+    uint32_t *kin = a.keys0, *kout = a.keys1;
+    int *iin = a.idx0, *iout = a.idx1;
+    for (int pass = 0; pass < 4; ++pass) {                                 // 32 key bits, the result lands in keys0 / idx0
+        hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(ST), 0, stream, kin, a.F, 8 * pass, gh, nb);
+        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, stream, gh, 256 * nb);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(ST), 0, stream, kin, iin, kout, iout, a.F, 8 * pass, gh, nb);
+        std::swap(kin, kout);
+        std::swap(iin, iout);
+    }
+    hipLaunchKernelGGL(k_build_tree, dim3((a.F + 255) / 256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_build_refit, dim3((a.F + 255) / 256), dim3(256), 0, stream, a);
 }
 
 }  // namespace nlos
