@@ -188,8 +188,11 @@ __global__ __launch_bounds__(512) void k_tile_bin(ForwardArgs a, int R, int from
 // themselves in a.retry and leave before binning anything; a second launch (`pass` = 1) with one workgroup
 // per CU and ~150 KB of LDS redoes exactly those (grazing views pile thousands of sliver triangles into a
 // few cells / tiles).
-template <int FEAT, int NCM = 0, bool TILED = false>
-__global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows_in_lds, int R, int cap, int pass = 0) {
+// PASS >= 0 fixes the pass at compile time (the single-workgroup grid: the usually idle retry launch then
+// shows up under its own kernel name in profiles); PASS = -1 takes it from the argument.
+template <int FEAT, int NCM = 0, bool TILED = false, int PASS = -1>
+__global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows_in_lds, int R, int cap, int pass_arg = 0) {
+    const int pass = PASS >= 0 ? PASS : pass_arg;
     // dynamic LDS: [ctl: ticket, bad, total, n_live (16 B)][row nbins f64][cells R*R+1 u32]
     //   [union { build: depth bound per 2x2 cells R2*R2 u32, block masks nblk u64 ;
     //            trace: 8 waves x (128 queued pairs + 2 mask words) }][entries cap u32]
@@ -737,15 +740,18 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
     size_t cap = (kGridLdsBudget - fixed) / 4;
     const size_t lds = fixed + cap * 4;
     const size_t lds_big = 150 * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(a.retry ? lds_big : lds));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM, false, 0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (a.retry)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM, false, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
     if (a.retry) (void)hipMemsetAsync(a.retry, 0, sizeof(int) * (size_t)a.src.L, stream);
     // one slot of slack: the walk reads entries in pairs and may touch the slot after the last list
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM>), dim3(a.src.L), dim3(512), lds, stream, a, rows_in_lds, R,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, false, 0>), dim3(a.src.L), dim3(512), lds, stream, a, rows_in_lds, R,
                        (int)cap - 1, 0);
     if (a.retry)      // sources whose cell lists overflowed: once more with the whole CU's LDS
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM>), dim3(a.src.L), dim3(512), lds_big, stream, a, rows_in_lds,
-                           R, (int)((lds_big - fixed) / 4) - 1, 1);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, false, 1>), dim3(a.src.L), dim3(512), lds_big, stream, a,
+                           rows_in_lds, R, (int)((lds_big - fixed) / 4) - 1, 1);
     return true;
 }
 

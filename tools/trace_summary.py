@@ -13,10 +13,10 @@ def main(path):
     rows = defaultdict(list)
     with open(path) as fh:
         for r in csv.DictReader(fh):
-            m = re.search(r"(k_[a-z_0-9]+)", r["Kernel_Name"])
+            m = re.search(r"(k_[a-z_0-9]+)(<[^>]*>)?", r["Kernel_Name"])
             if not m:
                 continue
-            rows[m.group(1)].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
+            rows[m.group(1) + (m.group(2) or "")].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
                                      int(r["VGPR_Count"]), int(r["LDS_Block_Size"]), int(r["Scratch_Size"])))
     out = {}
     for k, v in rows.items():
