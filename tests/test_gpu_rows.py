@@ -689,3 +689,29 @@ def test_render_step_is_hip_graph_capturable(bunny):
     assert (out["t"] - t2).abs().max().item() <= 1e-13 * t2.max().item()
     assert rel_l2(grad.cpu().numpy(), g2.cpu().numpy()) <= 1e-9
     assert (t2 - t_ref).abs().max().item() > 0          # the replay really rendered the moved mesh
+
+
+def test_two_contexts_on_two_streams_do_not_interfere(bunny, mannequin):
+    """Contexts own all their scratch; renders enqueued on different streams (different meshes, sizes and
+    back-ends) may overlap on the GPU without touching each other's state."""
+    import torch
+    from nlos_surface_optimization_amd import device as nd
+    dev = torch.device("cuda", 0)
+    jobs = []
+    for (v, f), ns, seed in ((bunny, 20000, 1), (mannequin, 4000, 2)):
+        r = nd.TransientRenderer(dev, seed=seed)
+        o, n = grid_sources(6, 0.25)
+        t = [torch.from_numpy(x).to(dev) for x in (o, n, v, f)]
+        ref, _ = r.render_transient(*t, ns, LB, UB, RES)
+        jobs.append((r, t, ns, ref.clone(), torch.cuda.Stream(device=dev)))
+    torch.cuda.synchronize()
+    outs = [[], []]
+    for it in range(6):
+        for k, (r, t, ns, ref, s) in enumerate(jobs):
+            with torch.cuda.stream(s):
+                out, _ = r.render_transient(*t, ns, LB, UB, RES, force_bvh=bool(it & 1) if k == 0 else False)
+                outs[k].append(out)
+    torch.cuda.synchronize()
+    for k, (r, t, ns, ref, s) in enumerate(jobs):
+        for out in outs[k]:
+            assert (out - ref).abs().max().item() <= 1e-13 * ref.max().item()
