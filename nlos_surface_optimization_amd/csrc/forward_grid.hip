@@ -63,6 +63,12 @@ struct BBoxF { float x0, x1, y0, y1; };
 constexpr int kSub = 6;          // sub-cell levels per axis
 constexpr int kIdxBits = 13;      // single-workgroup grid: 7 depth bits
 constexpr int kIdxBitsTiled = 14; // tiled grid: subsets up to 16383 triangles, 6 depth bits
+#ifndef NLOS_EXACT_ROUND
+#define NLOS_EXACT_ROUND 128
+#endif
+constexpr int kRound = NLOS_EXACT_ROUND;   // pairs per exact-test round: two per lane keep two record gathers in flight
+constexpr int kQueueCap = kRound + 64;      // a trip appends at most 64 pairs per slot before the drain check
+constexpr int kQueueWords = kQueueCap + 2;  // + the wave's 64-bit occlusion mask
 
 __device__ __forceinline__ uint32_t make_entry(const GridView& g, const BBoxF& bb, int xx, int yy, uint32_t zq, int k) {
     // the box is widened by 0.02 sub-cells: > 50x the fp32 error of the two projections (rcp, 1 ulp)
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     uint32_t* s_zc = s_union;                                                   // build phase
     unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(s_zc + ((R2 * R2 + 1) & ~1));
     uint32_t* s_queue = s_union;                                                // trace phase
-    const int union_words = max(((R2 * R2 + 1) & ~1) + 2 * mask_blocks, 8 * 130);
+    const int union_words = max(((R2 * R2 + 1) & ~1) + 2 * mask_blocks, 8 * kQueueWords);
     uint32_t* s_ent = s_union + ((union_words + 1) & ~1);
     uint16_t* g_live = a.live + (size_t)blockIdx.x * (TILED ? a.tile_cap : F);
     uint32_t* tl = TILED ? a.tile_list + (size_t)blockIdx.x * a.tile_cap : nullptr;
@@ -485,8 +491,8 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
 #define TMARK() do { } while (0)
 #define TACC(v) do { } while (0)
 #endif
-    uint32_t* wq = s_queue + wave * 128;                 // this wave's pair queue (aliases the build-phase tables)
-    uint32_t* wocc = s_queue + nwaves * 128 + wave * 2;  // this wave's 64-bit occlusion mask
+    uint32_t* wq = s_queue + wave * kQueueCap;           // this wave's pair queue (aliases the build-phase tables)
+    uint32_t* wocc = s_queue + nwaves * kQueueCap + wave * 2;  // this wave's 64-bit occlusion mask
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     for (;;) {
@@ -601,16 +607,20 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
 #endif
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const uint32_t pr = wq[lane < n ? lane : 0];
-                const int owner = (int)(pr >> 16), k = (int)(pr & 0xFFFFu);
-                const V3 od = mk(__shfl(dir.x, owner), __shfl(dir.y, owner), __shfl(dir.z, owner));
-                const float ot = __shfl(t_self, owner);
-                const int ofid = __shfl(f.fid, owner);
-                if (lane < n) {
-                    const int kg = gid(k);
-                    const Tri tk = load_tri(a.sc.tris, kg);
-                    if (tri_occludes(tk, o, od, ot, ofid, a.sc.face_id, kg))
-                        atomicOr(&wocc[owner >> 5], 1u << (owner & 31));
+#pragma unroll
+                for (int h = 0; h < kRound / 64; ++h) {
+                    const int qi = lane + 64 * h;
+                    const uint32_t pr = wq[qi < n ? qi : 0];
+                    const int owner = (int)(pr >> 16), k = (int)(pr & 0xFFFFu);
+                    const V3 od = mk(__shfl(dir.x, owner), __shfl(dir.y, owner), __shfl(dir.z, owner));
+                    const float ot = __shfl(t_self, owner);
+                    const int ofid = __shfl(f.fid, owner);
+                    if (qi < n) {
+                        const int kg = gid(k);
+                        const Tri tk = load_tri(a.sc.tris, kg);
+                        if (tri_occludes(tk, o, od, ot, ofid, a.sc.face_id, kg))
+                            atomicOr(&wocc[owner >> 5], 1u << (owner & 31));
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -627,12 +637,12 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
                 if (m) {
                     if (pass) wq[qn + __popcll(m & lt_mask)] = ((uint32_t)lane << 16) | (uint32_t)k;
                     qn += __popcll(m);
-                    if (qn >= 64) {
+                    if (qn >= kRound) {
                         TACC(ts);
-                        exact_round(64);
+                        exact_round(kRound);
                         TACC(tx);
-                        qn -= 64;
-                        const uint32_t mv = wq[64 + (lane < qn ? lane : 0)];
+                        qn -= kRound;
+                        const uint32_t mv = wq[kRound + (lane < qn ? lane : 0)];       // qn < 64 left over
                         __builtin_amdgcn_wave_barrier();
                         if (lane < qn) wq[lane] = mv;
                     }
@@ -733,7 +743,7 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
     const size_t nblk = ((size_t)a.sc.F + 63) / 64;
     const size_t R2 = ((size_t)R + 1) / 2;
     size_t union_words = ((R2 * R2 + 1) & ~(size_t)1) + 2 * nblk;
-    if (union_words < 8 * 130) union_words = 8 * 130;
+    if (union_words < 8 * kQueueWords) union_words = 8 * kQueueWords;
     const size_t fixed = 32 + (rows_in_lds ? (size_t)a.sp.nbins * sizeof(double) : 0) + (((size_t)R * R + 2) & ~(size_t)1) * 4 +
                          ((union_words + 1) & ~(size_t)1) * 4;
     if (fixed + 4 * 2 * (size_t)a.sc.F > kGridLdsBudget || !a.live) return false;      // want room for >= 2 entries per face
@@ -768,7 +778,7 @@ bool forward_tiled_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t str
     const size_t R2 = (R + 1) / 2;
     const size_t mask_blocks = std::max(((size_t)a.tile_cap + 63) / 64, ((size_t)a.sc.F + 63) / 64);
     size_t union_words = ((R2 * R2 + 1) & ~(size_t)1) + 2 * mask_blocks;
-    if (union_words < 8 * 130) union_words = 8 * 130;
+    if (union_words < 8 * kQueueWords) union_words = 8 * kQueueWords;
     const size_t fixed = 32 + (rows_in_lds ? (size_t)a.sp.nbins * sizeof(double) : 0) + (((size_t)R * R + 2) & ~(size_t)1) * 4 +
                          ((union_words + 1) & ~(size_t)1) * 4;
     if (fixed + 4 * 4096 > kGridLdsBudget) return false;
