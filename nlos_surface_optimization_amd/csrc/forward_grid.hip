@@ -67,6 +67,10 @@ constexpr int kIdxBitsTiled = 14; // tiled grid: subsets up to 16383 triangles, 
 #define NLOS_EXACT_ROUND 128
 #endif
 constexpr int kRound = NLOS_EXACT_ROUND;   // pairs per exact-test round: two per lane keep two record gathers in flight
+#ifndef NLOS_SCAN_WIDTH
+#define NLOS_SCAN_WIDTH 4
+#endif
+constexpr int kScan = NLOS_SCAN_WIDTH;      // cell-list entries per trip of the lockstep walk
 constexpr int kQueueCap = kRound + 64;      // a trip appends at most 64 pairs per slot before the drain check
 constexpr int kQueueWords = kQueueCap + 2;  // + the wave's 64-bit occlusion mask
 
@@ -648,28 +652,32 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
                     }
                 }
             };
-            // two entries per trip (one ds_read2_b32): halves the loop overhead of the lockstep walk
+            // kScan entries per trip: the lockstep walk pays its loop overhead (any(), branch, counters) once per
+            // trip; lists average 24 entries, so wider trips waste more slots at the end (2: 2.49 ms, 4: 2.43 ms)
             while (__any(e < e1)) {
-                bool p0 = false, p1 = false;
-                int k0 = 0, k1 = 0;
+                bool p[kScan];
+                int k[kScan];
+#pragma unroll
+                for (int q = 0; q < kScan; ++q) { p[q] = false; k[q] = 0; }
                 if (e < e1) {
-                    const uint32_t w0 = s_ent[e], w1 = s_ent[e + 1];
-                    k0 = (int)(w0 & imask);
-                    k1 = (int)(w1 & imask);
-                    p0 = (w0 <= rlim) & ((w0 & rmask) == rmask) & (k0 != j);
-                    p1 = (e + 1 < e1) & (w1 <= rlim) & ((w1 & rmask) == rmask) & (k1 != j);
+#pragma unroll
+                    for (int q = 0; q < kScan; ++q) {
+                        const uint32_t w = s_ent[e + q];
+                        k[q] = (int)(w & imask);
+                        p[q] = (e + q < e1) & (w <= rlim) & ((w & rmask) == rmask) & (k[q] != j);
+                    }
 #ifdef NLOS_FWD_STAMPS
-                    if (grid_ray) c_pairs += (e + 1 < e1) ? 2 : 1;
+                    if (grid_ray) c_pairs += min(kScan, (int)(e1 - e));
 #endif
-                    e += 2;
+                    e += kScan;
                 }
 #ifdef NLOS_FWD_STAMPS
                 if (lane == 0) c_iters += 1;
-                if (p0) c_mt += 1;
-                if (p1) c_mt += 1;
+#pragma unroll
+                for (int q = 0; q < kScan; ++q) if (p[q]) c_mt += 1;
 #endif
-                push(p0, k0);
-                push(p1, k1);
+#pragma unroll
+                for (int q = 0; q < kScan; ++q) push(p[q], k[q]);
             }
             TACC(ts);
             if (qn > 0) exact_round(qn);
@@ -756,12 +764,12 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM, false, 1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
     if (a.retry) (void)hipMemsetAsync(a.retry, 0, sizeof(int) * (size_t)a.src.L, stream);
-    // one slot of slack: the walk reads entries in pairs and may touch the slot after the last list
+    // kScan slots of slack: the walk reads kScan entries per trip and may touch the slots after the last list
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, false, 0>), dim3(a.src.L), dim3(512), lds, stream, a, rows_in_lds, R,
-                       (int)cap - 1, 0);
+                       (int)cap - kScan, 0);
     if (a.retry)      // sources whose cell lists overflowed: once more with the whole CU's LDS
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, false, 1>), dim3(a.src.L), dim3(512), lds_big, stream, a,
-                           rows_in_lds, R, (int)((lds_big - fixed) / 4) - 1, 1);
+                           rows_in_lds, R, (int)((lds_big - fixed) / 4) - kScan, 1);
     return true;
 }
 
@@ -796,9 +804,9 @@ bool forward_tiled_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t str
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, true>), dim3((unsigned)nwg), dim3(512), lds, stream, a, rows_in_lds, R,
-                       (int)cap - 1, 0);
+                       (int)cap - kScan, 0);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, true>), dim3((unsigned)nwg), dim3(512), lds_big, stream, a, rows_in_lds,
-                       R, (int)cap_big - 1, 1);
+                       R, (int)cap_big - kScan, 1);
     return true;
 }
 
