@@ -430,7 +430,11 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     if (TILED && tid == 0 && a.dbg && !use_grid && !ident) atomicAdd((unsigned long long*)&a.dbg[20], 1ull);   // entry overflow
     if (TILED && tid == 0 && a.dbg) atomicMax((unsigned long long*)&a.dbg[21], (unsigned long long)s_ctl[2]);
 #endif
-    constexpr int NB = 16;                                   // buckets of 4 entries
+#ifndef NLOS_NB
+#define NLOS_NB 16
+#define NLOS_NB_SHIFT 2
+#endif
+    constexpr int NB = NLOS_NB;                              // buckets of (1 << NLOS_NB_SHIFT) entries
     auto face_bucket = [&](int j) -> int {
         if (!use_grid) return 0;
         // longest list among the cells under the face's projected bounding box
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
                 const int c = yy * R + xx;
                 n = max(n, s_cell[c] - (c > 0 ? s_cell[c - 1] : 0u));
             }
-        return (NB - 1) - (int)min(n >> 2, (uint32_t)(NB - 1));   // bucket 0 = longest lists
+        return (NB - 1) - (int)min(n >> NLOS_NB_SHIFT, (uint32_t)(NB - 1));   // bucket 0 = longest lists
     };
     if (tid < 2 * NB) s_scan[tid] = 0u;
     __syncthreads();
