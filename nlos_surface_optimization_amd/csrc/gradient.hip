@@ -47,7 +47,7 @@ __global__ __launch_bounds__(NLOS_GRAD_NT, NLOS_GRAD_WPS) void k_gradient(Gradie
         for (int i = threadIdx.x; i < 3 * V; i += blockDim.x) s_grad[i] = 0.0;
     double scalar_acc = 0.0;
     TapTables tt;
-    tt.delta = s_delta; tt.p0 = s_p0; tt.p1 = s_p1; tt.K = K; tt.two_rs = a.two_rs; tt.r_over_res = a.r_over_res;
+    tt.delta = s_delta; tt.p0 = s_p0; tt.p1 = s_p1; tt.K = K; tt.two_rs = a.two_rs; tt.r_over_res = a.r_over_res; tt.refine = a.refine;
 
     for (int l = blockIdx.x; l < a.src.L; l += gridDim.x) {
         __syncthreads();                    // previous source done with s_diff
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kFmThreads) void k_gradient_fm(GradientArgs a, int 
     for (int i = tid; i < K; i += kFmThreads) s_delta[i] = a.tap_delta[i];
     for (int i = tid; i <= K; i += kFmThreads) { s_p0[i] = a.tap_p0[i]; s_p1[i] = a.tap_p1[i]; }
     TapTables tt;
-    tt.delta = s_delta; tt.p0 = s_p0; tt.p1 = s_p1; tt.K = K; tt.two_rs = a.two_rs; tt.r_over_res = a.r_over_res;
+    tt.delta = s_delta; tt.p0 = s_p0; tt.p1 = s_p1; tt.K = K; tt.two_rs = a.two_rs; tt.r_over_res = a.r_over_res; tt.refine = a.refine;
 
     for (int lb0 = l0; lb0 < l1; lb0 += kFmBatch) {
         const int nb = min(kFmBatch, l1 - lb0);

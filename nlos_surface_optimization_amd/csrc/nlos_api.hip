@@ -628,6 +628,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         const bool v1 = mode == NLOS_MODE_GRADIENT_V1;
         ga.two_rs = v1 ? 0 : 2 * a->refine_scale * a->sigma_bin;
         ga.r_over_res = v1 ? 1.0 : (double)a->refine_scale / (double)res;
+        ga.refine = v1 ? 1 : a->refine_scale;
         ga.v1_style = mode == NLOS_MODE_GRADIENT_V1 ? 1 : 0;
         ga.vertex_num = a->vertex_num;
         ga.diff = diff_ptr;

@@ -127,6 +127,7 @@ struct GradientArgs {
     int K;
     int two_rs;              // 2*refine*sigma_bin (index of the centre tap)
     double r_over_res;       // refine / resolution
+    int refine;              // taps per bin (consecutive bin boundaries are this many taps apart)
     int normal_term;         // 0/1 (already resolved)
     int v1_style;            // 1: G1 (t1 without albedo)
     int mode;                // 0 vertex gradient [V,3], 1 scalar albedo, 2 scalar alpha, 3 single vertex per bin,

@@ -252,7 +252,7 @@ struct TapTables {
     const double* delta;   // [K]
     const double* p0;      // [K+1]
     const double* p1;      // [K+1]
-    int K, two_rs;
+    int K, two_rs, refine;
     double r_over_res;     // refine / res
 };
 
@@ -264,22 +264,43 @@ __device__ __forceinline__ void grouped_taps(const TapTables& tt, const double* 
     const int K = tt.K;
     const int b_first = tap_bin(twoh, tt.delta[0], lbd, resd, inv_res);
     const int b_last = tap_bin(twoh, tt.delta[K - 1], lbd, resd, inv_res);
+    // first tap whose bin exceeds b: delta_i >= (b+1)*res + lb - 2h, i.e. a boundary y (in continuous tap
+    // index, minus two_rs); consecutive boundaries are exactly `refine` taps apart
+    const double thr0 = ((double)(b_first + 1) * resd + lbd) - twoh;
+    const double y0 = thr0 * tt.r_over_res;
+    const double yc0 = ceil(y0);
+    // delta_i carries the fp32 rounding of (i - two_rs) * res / refine (<= ~1e-6 taps): the closed form is the
+    // reference's per-tap assignment unless the boundary is that close to a tap.  All boundaries of a sample
+    // share the fractional part of y0 (to ~1e-13), so one test decides for the whole sample.
+    if (b_first == b_last || (yc0 - y0 >= 1e-4 && y0 - (yc0 - 1.0) >= 1e-4)) {
+        int ic = (int)yc0 + tt.two_rs;
+        int i_start = 0;
+        double q0 = tt.p0[0], q1 = tt.p1[0];
+        for (int b = b_first; b <= b_last; ++b) {
+            const int ie = b < b_last ? max(i_start, min(K, ic)) : K;
+            const double e0 = tt.p0[ie], e1 = tt.p1[ie];
+            if (b >= 0 && b < T) {
+                const double dd = (double)(float)((-2) * s_diff[b]);
+                s0 += dd * (e0 - q0);
+                s1 += dd * (e1 - q1);
+            }
+            q0 = e0; q1 = e1;
+            i_start = ie;
+            ic += tt.refine;
+        }
+        return;
+    }
+    // a boundary within 1e-4 of a tap: every boundary verified with the exact per-tap bin formula
     int i_start = 0;
     for (int b = b_first; b <= b_last; ++b) {
         int ie = K;
         if (b < b_last) {
-            // first tap whose bin exceeds b: delta_i >= (b+1)*res + lb - 2h
             const double thr = ((double)(b + 1) * resd + lbd) - twoh;
-            const double y = thr * tt.r_over_res;          // boundary in (continuous) tap index, minus two_rs
-            const double yc = ceil(y);
-            int ic = (int)yc + tt.two_rs;
+            const double y = thr * tt.r_over_res;
+            int ic = (int)ceil(y) + tt.two_rs;
             ic = max(i_start, min(K, ic));
-            // delta_i carries the fp32 rounding of (i - two_rs) * res / refine (<= ~1e-6 taps): the closed
-            // form is the reference's per-tap assignment unless the boundary is that close to a tap
-            if (yc - y < 1e-4 || y - (yc - 1.0) < 1e-4) {
-                while (ic > i_start && tap_bin(twoh, tt.delta[ic - 1], lbd, resd, inv_res) > b) --ic;
-                while (ic < K && tap_bin(twoh, tt.delta[ic], lbd, resd, inv_res) <= b) ++ic;
-            }
+            while (ic > i_start && tap_bin(twoh, tt.delta[ic - 1], lbd, resd, inv_res) > b) --ic;
+            while (ic < K && tap_bin(twoh, tt.delta[ic], lbd, resd, inv_res) <= b) ++ic;
             ie = ic;
         }
         if (b >= 0 && b < T && ie > i_start) {
