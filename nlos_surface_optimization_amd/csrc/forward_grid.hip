@@ -227,9 +227,14 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     uint32_t* s_queue = s_union;                                                // trace phase
     const int union_words = max(((R2 * R2 + 1) & ~1) + 2 * mask_blocks, 8 * kQueueWords);
     uint32_t* s_ent = s_union + ((union_words + 1) & ~1);
+    // build phase only: list length per cell (clamped to 255) in the part of the union the masks leave free,
+    // so that the fill pass can bucket the live faces while it has their projection at hand
+    uint8_t* s_len8 = reinterpret_cast<uint8_t*>(s_mask + mask_blocks);
+    const bool len_ok = (((R2 * R2 + 1) & ~1) + 2 * mask_blocks) * 4 + ncell <= union_words * 4;
     uint16_t* g_live = a.live + (size_t)blockIdx.x * (TILED ? a.tile_cap : F);
     uint32_t* tl = TILED ? a.tile_list + (size_t)blockIdx.x * a.tile_cap : nullptr;
     __shared__ uint32_t s_scan[512];
+    __shared__ uint32_t s_bkt[32];                   // live faces per list-length bucket, then the write cursors
 
     const int l = TILED ? (int)(blockIdx.x / (unsigned)ntiles) : (int)blockIdx.x;
     const int tid = threadIdx.x, NT = blockDim.x;
@@ -283,6 +288,7 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     for (int i = tid; i <= ncell; i += NT) s_cell[i] = 0u;
     for (int i = tid; i < R2 * R2; i += NT) s_zc[i] = 0u;
     if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = frame_ok ? 0 : 1; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[4] = 0; }
+    if (tid < 32) s_bkt[tid] = 0u;
     __syncthreads();
 
     // Fl faces are iterated by this workgroup; `ident`: local index == sorted face index
@@ -390,7 +396,12 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
             __syncthreads();
         }
         uint32_t run = s_scan[tid] - sum;
-        for (int c = c0; c < c1; ++c) { uint32_t n = s_cell[c]; s_cell[c] = run; run += n; }
+        for (int c = c0; c < c1; ++c) {
+            uint32_t n = s_cell[c];
+            s_cell[c] = run;
+            run += n;
+            if (len_ok) s_len8[c] = (uint8_t)min(n, 255u);
+        }
         if (tid == NT - 1) { s_ctl[2] = (int)s_scan[tid]; if ((int)s_scan[tid] > cap) s_ctl[1] = 1; }
     }
     __syncthreads();
@@ -400,8 +411,18 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     }
     FWD_STAMP();   // 2: scans
     // ---- fill pass: s_cell[c] is the write cursor, afterwards the END of cell c ------------------
+    // Live faces are bucketed here as well (longest list under the face's projected bounding box, see the
+    // live list below): the bucket of the it-th face of a thread is kept as a nibble for the placement loop.
+#ifndef NLOS_NB
+#define NLOS_NB 16
+#define NLOS_NB_SHIFT 2
+#endif
+    constexpr int NB = NLOS_NB;                              // buckets of (1 << NLOS_NB_SHIFT) entries
+    const bool fill_buckets = len_ok && compact;
+    unsigned long long nib0 = 0ull, nib1 = 0ull;
     if (frame_ok && s_ctl[1] == 0) {
-        for (int jl = tid; jl < Fl; jl += NT) {
+        int it = 0;
+        for (int jl = tid; jl < Fl; jl += NT, ++it) {
             const int j = gid(jl);
             const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
             const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
@@ -417,6 +438,17 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
                     s_ent[pos] = make_entry(g, bb, xx, yy, zq, jl);
                 }
             });
+            if (fill_buckets && ((s_mask[jl >> 6] >> (jl & 63)) & 1ull)) {
+                const int cx0 = cell_coord(bb.x0, g.gx0, g.inv_cw, R), cx1 = cell_coord(bb.x1, g.gx0, g.inv_cw, R);
+                const int cy0 = cell_coord(bb.y0, g.gy0, g.inv_ch, R), cy1 = cell_coord(bb.y1, g.gy0, g.inv_ch, R);
+                uint32_t n = 0;
+                for (int yy = cy0; yy <= cy1; ++yy)
+                    for (int xx = cx0; xx <= cx1; ++xx) n = max(n, (uint32_t)s_len8[yy * R + xx]);
+                const int bkt = (NB - 1) - (int)min(n >> NLOS_NB_SHIFT, (uint32_t)(NB - 1));   // bucket 0 = longest lists
+                atomicAdd(&s_bkt[bkt], 1u);
+                if (it < 16) nib0 |= (unsigned long long)bkt << (4 * it);
+                else nib1 |= (unsigned long long)bkt << (4 * (it - 16));
+            }
         }
     }
     __syncthreads();
@@ -430,11 +462,6 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     if (TILED && tid == 0 && a.dbg && !use_grid && !ident) atomicAdd((unsigned long long*)&a.dbg[20], 1ull);   // entry overflow
     if (TILED && tid == 0 && a.dbg) atomicMax((unsigned long long*)&a.dbg[21], (unsigned long long)s_ctl[2]);
 #endif
-#ifndef NLOS_NB
-#define NLOS_NB 16
-#define NLOS_NB_SHIFT 2
-#endif
-    constexpr int NB = NLOS_NB;                              // buckets of (1 << NLOS_NB_SHIFT) entries
     auto face_bucket = [&](int j) -> int {
         if (!use_grid) return 0;
         // longest list among the cells under the face's projected bounding box
@@ -453,21 +480,24 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
             }
         return (NB - 1) - (int)min(n >> NLOS_NB_SHIFT, (uint32_t)(NB - 1));   // bucket 0 = longest lists
     };
-    if (tid < 2 * NB) s_scan[tid] = 0u;
-    __syncthreads();
-    for (int b = wave; compact && b < nblocks; b += nwaves) {
-        if ((s_mask[b] >> lane) & 1ull) atomicAdd(&s_scan[face_bucket((b << 6) + lane)], 1u);
+    const bool have_nibbles = fill_buckets && use_grid;      // the fill pass ran and counted the buckets
+    for (int b = wave; compact && !have_nibbles && b < nblocks; b += nwaves) {
+        if ((s_mask[b] >> lane) & 1ull) atomicAdd(&s_bkt[face_bucket((b << 6) + lane)], 1u);
     }
     __syncthreads();
     if (tid == 0) {
         uint32_t run = 0;
-        for (int q = 0; q < NB; ++q) { s_scan[NB + q] = run; run += s_scan[q]; }
+        for (int q = 0; q < NB; ++q) { s_bkt[NB + q] = run; run += s_bkt[q]; }
     }
     __syncthreads();
-    for (int b = wave; compact && b < nblocks; b += nwaves) {
-        if ((s_mask[b] >> lane) & 1ull) {
-            const int j = (b << 6) + lane;
-            g_live[atomicAdd(&s_scan[NB + face_bucket(j)], 1u)] = (uint16_t)j;
+    {
+        int it = 0;                                          // block b = wave + it * nwaves holds faces tid + it * NT
+        for (int b = wave; compact && b < nblocks; b += nwaves, ++it) {
+            if ((s_mask[b] >> lane) & 1ull) {
+                const int j = (b << 6) + lane;
+                const int bkt = have_nibbles ? (int)(((it < 16 ? nib0 >> (4 * it) : nib1 >> (4 * (it - 16)))) & 15ull) : face_bucket(j);
+                g_live[atomicAdd(&s_bkt[NB + bkt], 1u)] = (uint16_t)j;
+            }
         }
     }
     __syncthreads();
@@ -741,8 +771,9 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     }
 }
 
-// LDS budget of the grid kernel: two 512-thread workgroups per CU (160 KiB / 2, minus slack)
-constexpr size_t kGridLdsBudget = 78 * 1024;
+// LDS budget of the grid kernel: two 512-thread workgroups per CU -- 160 KiB / 2, minus the kernel's static
+// arrays (s_scan 2 KiB, s_bkt 128 B); one byte more and only one workgroup fits a CU (2.4 -> 3.9 ms)
+constexpr size_t kGridLdsBudget = 78 * 1024 - 128;
 
 template <int FEAT, int NCM = 0>
 bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {

@@ -209,7 +209,8 @@ def test_device_tensor_path_sharding_and_autograd(bunny, orc):
                                     total_sources=9)
         rows.append(t)
         gsum += g
-    assert torch.equal(torch.cat(rows), tr)
+    # rows depend on their own source only; fp64 atomics land in arrival order, so equal to rounding
+    assert rel_l2(torch.cat(rows).cpu().numpy(), tr.cpu().numpy()) <= 1e-12
     assert rel_l2(gsum.cpu().numpy(), grad.cpu().numpy()) <= 1e-12
     # autograd: d/dv of sum(w * (data - T)^2) / L equals the reference-style gradient
     vp = tv.clone().requires_grad_(True)
@@ -574,7 +575,8 @@ def test_config4_shape_mannequin_nonconfocal_sharded(mannequin, orc):
                                     source_offset=lo, total_sources=16)
         rows.append(t)
         gsum += g
-    assert torch.equal(torch.cat(rows), tr)
+    # rows depend on their own source only; fp64 atomics land in arrival order, so equal to rounding
+    assert rel_l2(torch.cat(rows).cpu().numpy(), tr.cpu().numpy()) <= 1e-12
     assert rel_l2(gsum.cpu().numpy(), grad.cpu().numpy()) <= 1e-12
 
 
