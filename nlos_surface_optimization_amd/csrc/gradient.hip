@@ -137,9 +137,9 @@ __global__ __launch_bounds__(NLOS_GRAD_NT, NLOS_GRAD_WPS) void k_gradient(Gradie
                         for (int q = 0; q < 3; ++q) {
                             V3 A1 = gv.t1 * bw[q] + ce[q];
                             V3 A2 = di * bw[q];
-                            acc[3 * q + 0] += (double)A1.x * s0 + (double)A2.x * s1;
-                            acc[3 * q + 1] += (double)A1.y * s0 + (double)A2.y * s1;
-                            acc[3 * q + 2] += (double)A1.z * s0 + (double)A2.z * s1;
+                            acc[3 * q + 0] = fma((double)A1.x, s0, fma((double)A2.x, s1, acc[3 * q + 0]));
+                            acc[3 * q + 1] = fma((double)A1.y, s0, fma((double)A2.y, s1, acc[3 * q + 1]));
+                            acc[3 * q + 2] = fma((double)A1.z, s0, fma((double)A2.z, s1, acc[3 * q + 2]));
                         }
                         continue;
                     }
@@ -217,9 +217,9 @@ __global__ __launch_bounds__(NLOS_GRAD_NT, NLOS_GRAD_WPS) void k_gradient(Gradie
                     for (int q = 0; q < 3; ++q) {
                         V3 A1 = gv.t1 * bw[q] + ce[q];
                         V3 A2 = di * bw[q];
-                        acc[3 * q + 0] += (double)A1.x * s0 + (double)A2.x * s1;
-                        acc[3 * q + 1] += (double)A1.y * s0 + (double)A2.y * s1;
-                        acc[3 * q + 2] += (double)A1.z * s0 + (double)A2.z * s1;
+                        acc[3 * q + 0] = fma((double)A1.x, s0, fma((double)A2.x, s1, acc[3 * q + 0]));
+                        acc[3 * q + 1] = fma((double)A1.y, s0, fma((double)A2.y, s1, acc[3 * q + 1]));
+                        acc[3 * q + 2] = fma((double)A1.z, s0, fma((double)A2.z, s1, acc[3 * q + 2]));
                     }
                 }
             }
@@ -364,9 +364,9 @@ __global__ __launch_bounds__(kFmThreads) void k_gradient_fm(GradientArgs a, int 
                     for (int q = 0; q < 3; ++q) {
                         const V3 A1 = gv.t1 * bw[q] + ce[q];
                         const V3 A2 = di * bw[q];
-                        acc[3 * q + 0] += (double)A1.x * s0 + (double)A2.x * s1;
-                        acc[3 * q + 1] += (double)A1.y * s0 + (double)A2.y * s1;
-                        acc[3 * q + 2] += (double)A1.z * s0 + (double)A2.z * s1;
+                        acc[3 * q + 0] = fma((double)A1.x, s0, fma((double)A2.x, s1, acc[3 * q + 0]));
+                        acc[3 * q + 1] = fma((double)A1.y, s0, fma((double)A2.y, s1, acc[3 * q + 1]));
+                        acc[3 * q + 2] = fma((double)A1.z, s0, fma((double)A2.z, s1, acc[3 * q + 2]));
                     }
                 }
             }

@@ -281,8 +281,8 @@ __device__ __forceinline__ void grouped_taps(const TapTables& tt, const double* 
             const double e0 = tt.p0[ie], e1 = tt.p1[ie];
             if (b >= 0 && b < T) {
                 const double dd = (double)(float)((-2) * s_diff[b]);
-                s0 += dd * (e0 - q0);
-                s1 += dd * (e1 - q1);
+                s0 = fma(dd, e0 - q0, s0);       // fp64 sums of fp32-exact products: fused or not is below 1e-16
+                s1 = fma(dd, e1 - q1, s1);
             }
             q0 = e0; q1 = e1;
             i_start = ie;
