@@ -51,7 +51,11 @@ __global__ __launch_bounds__(NLOS_GRAD_NT, NLOS_GRAD_WPS) void k_gradient(Gradie
 
     for (int l = blockIdx.x; l < a.src.L; l += gridDim.x) {
         __syncthreads();                    // previous source done with s_diff
-        for (int i = threadIdx.x; i < T; i += blockDim.x) s_diff[i] = a.diff[(size_t)l * T + i];
+        // vertex-gradient modes read the row only as (float)(-2 d): rounded once here instead of once per tap group
+        for (int i = threadIdx.x; i < T; i += blockDim.x) {
+            const double d = a.diff[(size_t)l * T + i];
+            s_diff[i] = (MODE == 0 || MODE == 4) ? (double)(float)((-2) * d) : d;
+        }
         if (threadIdx.x == 0) *s_next = 0;
         // faces with at least one accepted sample, compacted in order (pass 1 left the masks)
         for (int b = wave; b < nblocks; b += nwaves) {
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(NLOS_GRAD_NT, NLOS_GRAD_WPS) void k_gradient(Gradie
                         s1 = 0.0;
                         const int i0 = max(0, -b0), i1 = min(K, T - b0);
                         for (int i = i0; i < i1; ++i) {
-                            const float dd = (float)((-2) * s_diff[b0 + i]);
+                            const float dd = (float)s_diff[b0 + i];      // (float)(-2 d), see the row load
                             s0 += (double)((float)s_delta[i] * dd);
                             s1 += (double)(((float)(s_p0[i] * m2i) / a.sp.res) * dd);
                         }
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(kFmThreads) void k_gradient_fm(GradientArgs a, int 
     for (int lb0 = l0; lb0 < l1; lb0 += kFmBatch) {
         const int nb = min(kFmBatch, l1 - lb0);
         __syncthreads();                                   // previous batch done with rows / list
-        for (int i = tid; i < nb * T; i += kFmThreads) s_rows[i] = a.diff[(size_t)lb0 * T + i];
+        for (int i = tid; i < nb * T; i += kFmThreads) s_rows[i] = (double)(float)((-2) * a.diff[(size_t)lb0 * T + i]);
         if (tid == 0) *s_cnt = 0;
         __syncthreads();
         // (source, face) items of this batch with at least one accepted sample

@@ -256,7 +256,8 @@ struct TapTables {
     double r_over_res;     // refine / res
 };
 
-__device__ __forceinline__ void grouped_taps(const TapTables& tt, const double* __restrict__ s_diff, int T,
+// s_m2diff: the residual row as (double)(float)(-2 d)
+__device__ __forceinline__ void grouped_taps(const TapTables& tt, const double* __restrict__ s_m2diff, int T,
                                              double twoh, double lbd, double resd, double inv_res,
                                              double& s0, double& s1) {
     s0 = 0.0;
@@ -280,7 +281,7 @@ __device__ __forceinline__ void grouped_taps(const TapTables& tt, const double* 
             const int ie = b < b_last ? max(i_start, min(K, ic)) : K;
             const double e0 = tt.p0[ie], e1 = tt.p1[ie];
             if (b >= 0 && b < T) {
-                const double dd = (double)(float)((-2) * s_diff[b]);
+                const double dd = s_m2diff[b];
                 s0 = fma(dd, e0 - q0, s0);       // fp64 sums of fp32-exact products: fused or not is below 1e-16
                 s1 = fma(dd, e1 - q1, s1);
             }
@@ -304,7 +305,7 @@ __device__ __forceinline__ void grouped_taps(const TapTables& tt, const double* 
             ie = ic;
         }
         if (b >= 0 && b < T && ie > i_start) {
-            double dd = (double)(float)((-2) * s_diff[b]);
+            const double dd = s_m2diff[b];
             s0 += dd * (tt.p0[ie] - tt.p0[i_start]);
             s1 += dd * (tt.p1[ie] - tt.p1[i_start]);
         }
