@@ -28,9 +28,10 @@ namespace nlos {
 namespace {
 
 constexpr int BT = 1024;          // build threads (one workgroup)
-constexpr int RBITS = 5;          // radix bits per pass
-constexpr int RDIG = 1 << RBITS;  // 32 digits
-constexpr int RPASS = 6;          // 30-bit keys
+constexpr int RBITS = 4;          // radix bits per pass
+constexpr int RDIG = 1 << RBITS;  // 16 digits: the counters (66 KB) leave room for keys and indices in LDS
+constexpr int RPASS = 8;          // 30-bit keys (an even number of passes: the result lands in the first buffer)
+constexpr int RCNT_WORDS = RDIG * BT + RDIG * BT / 32 + 32;   // skewed counter table
 
 __device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
     v = (v * 0x00010001u) & 0xFF0000FFu;
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256) void k_build_refit(BuildArgs a) {
 }
 
 __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, int split) {
-    extern __shared__ uint32_t s_dyn[];       // radix counters [RDIG * BT] (128 KB)
+    extern __shared__ uint32_t s_dyn[];       // radix counters [RDIG * BT] (64 KB + skew), sort buffers; later the LDS refit
     __shared__ uint32_t s_wsum[BT / 64];
     __shared__ float s_red[6 * 16];           // per-wave bounds
     __shared__ float s_bounds[8];             // lo[3], hi[3], pad
@@ -372,10 +373,14 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, 
     NLOS_STAMP();
 
     // ---- phase 2: Morton keys ---------------------------------------------------
-    uint32_t* keys_in = a.keys0;
-    uint32_t* keys_out = a.keys1;
-    int* idx_in = a.idx0;
-    int* idx_out = a.idx1;
+    // Keys and (16-bit) indices live in LDS behind the counters while they are sorted: a pass then costs
+    // ~100 LDS operations per thread instead of a round trip through L2 (sort 119 k -> ~20 k cycles at F = 5 k).
+    // Meshes too large for that (never the case below the LDS-refit limit) ping-pong through global scratch.
+    const bool sort_in_lds = F <= 65535 && RCNT_WORDS + 3 * F + 4 <= lds_words;
+    uint32_t* s_keyA = s_dyn + RCNT_WORDS;
+    uint32_t* s_keyB = s_keyA + F;
+    uint16_t* s_idxA = reinterpret_cast<uint16_t*>(s_keyB + F);
+    uint16_t* s_idxB = s_idxA + F + (F & 1);
     {
         float sx = s_bounds[3] - s_bounds[0], sy = s_bounds[4] - s_bounds[1], sz = s_bounds[5] - s_bounds[2];
         float ix = sx > 0 ? 1.0f / sx : 0.0f, iy = sy > 0 ? 1.0f / sy : 0.0f, iz = sz > 0 ? 1.0f / sz : 0.0f;
@@ -391,8 +396,9 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, 
             uint32_t qx = (uint32_t)fminf(fmaxf(nx * 1024.0f, 0.0f), 1023.0f);
             uint32_t qy = (uint32_t)fminf(fmaxf(ny * 1024.0f, 0.0f), 1023.0f);
             uint32_t qz = (uint32_t)fminf(fmaxf(nz * 1024.0f, 0.0f), 1023.0f);
-            keys_in[f] = (expand_bits(qx) << 2) | (expand_bits(qy) << 1) | expand_bits(qz);
-            idx_in[f] = f;
+            const uint32_t key = (expand_bits(qx) << 2) | (expand_bits(qy) << 1) | expand_bits(qz);
+            if (sort_in_lds) { s_keyA[f] = key; s_idxA[f] = (uint16_t)f; }
+            else { a.keys0[f] = key; a.idx0[f] = f; }
         }
     }
     __syncthreads();
@@ -402,36 +408,47 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, 
     // counters are laid out [digit][thread]; the exclusive scan runs over that flat order
     const int chunk = (F + BT - 1) / BT;
     const int c0 = min(tid * chunk, F), c1 = min(c0 + chunk, F);
-    for (int pass = 0; pass < RPASS; ++pass) {
-        const int shift = pass * RBITS;
-        for (int d = 0; d < RDIG; ++d) s_cnt[SK(d * BT + tid)] = 0;
-        for (int i = c0; i < c1; ++i) s_cnt[SK(((keys_in[i] >> shift) & (RDIG - 1)) * BT + tid)] += 1;
-        __syncthreads();
-        // thread t owns flat entries [RDIG*t, RDIG*t + RDIG)
-        uint32_t sum = 0;
-        for (int q = 0; q < RDIG; ++q) sum += s_cnt[SK(tid * RDIG + q)];
-        uint32_t incl = sum;
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
+    auto radix_sort = [&](auto* keys_in, auto* keys_out, auto* idx_in, auto* idx_out) {
+        for (int pass = 0; pass < RPASS; ++pass) {
+            const int shift = pass * RBITS;
+            for (int d = 0; d < RDIG; ++d) s_cnt[SK(d * BT + tid)] = 0;
+            for (int i = c0; i < c1; ++i) s_cnt[SK(((keys_in[i] >> shift) & (RDIG - 1)) * BT + tid)] += 1;
+            __syncthreads();
+            // thread t owns flat entries [RDIG*t, RDIG*t + RDIG)
+            uint32_t sum = 0;
+            for (int q = 0; q < RDIG; ++q) sum += s_cnt[SK(tid * RDIG + q)];
+            uint32_t incl = sum;
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t v = __shfl_up(incl, off);
+                if (lane >= off) incl += v;
+            }
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            uint32_t wbase = 0;
+            for (int w = 0; w < wave; ++w) wbase += s_wsum[w];
+            uint32_t run = wbase + incl - sum;
+            for (int q = 0; q < RDIG; ++q) { uint32_t n = s_cnt[SK(tid * RDIG + q)]; s_cnt[SK(tid * RDIG + q)] = run; run += n; }
+            __syncthreads();
+            for (int i = c0; i < c1; ++i) {
+                uint32_t k = keys_in[i];
+                uint32_t dst = s_cnt[SK(((k >> shift) & (RDIG - 1)) * BT + tid)]++;
+                keys_out[dst] = k;
+                idx_out[dst] = idx_in[i];
+            }
+            __syncthreads();
+            auto* tk = keys_in; keys_in = keys_out; keys_out = tk;
+            auto* ti = idx_in; idx_in = idx_out; idx_out = ti;
         }
-        if (lane == 63) s_wsum[wave] = incl;
+    };
+    if (sort_in_lds) {
+        radix_sort(s_keyA, s_keyB, s_idxA, s_idxB);
+        for (int f = tid; f < F; f += BT) { a.keys0[f] = s_keyA[f]; a.idx0[f] = (int)s_idxA[f]; }
         __syncthreads();
-        uint32_t wbase = 0;
-        for (int w = 0; w < wave; ++w) wbase += s_wsum[w];
-        uint32_t run = wbase + incl - sum;
-        for (int q = 0; q < RDIG; ++q) { uint32_t n = s_cnt[SK(tid * RDIG + q)]; s_cnt[SK(tid * RDIG + q)] = run; run += n; }
-        __syncthreads();
-        for (int i = c0; i < c1; ++i) {
-            uint32_t k = keys_in[i];
-            uint32_t dst = s_cnt[SK(((k >> shift) & (RDIG - 1)) * BT + tid)]++;
-            keys_out[dst] = k;
-            idx_out[dst] = idx_in[i];
-        }
-        __syncthreads();
-        uint32_t* tk = keys_in; keys_in = keys_out; keys_out = tk;
-        int* ti = idx_in; idx_in = idx_out; idx_out = ti;
+    } else {
+        radix_sort(a.keys0, a.keys1, a.idx0, a.idx1);
     }
+    uint32_t* keys_in = a.keys0;              // the sorted keys / order (even number of passes)
+    int* idx_in = a.idx0;
     const uint32_t* keys = keys_in;           // == a.keys0 / a.idx0 (even number of passes)
     const int* order = idx_in;
     NLOS_STAMP();
@@ -449,20 +466,22 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, 
     const bool lds_refit = n_int > 0 && 7 * n_int <= lds_words;
     uint32_t* s_par = s_dyn;                     // [n_int]
     uint32_t* s_box = s_dyn + n_int;             // [6 * n_int]: 0..2 min keys, 3..5 max keys
-    if (lds_refit) {
-        for (int i = tid; i < n_int; i += BT) {
-            for (int c = 0; c < 3; ++c) { s_box[6 * i + c] = 0xFFFFFFFFu; s_box[6 * i + 3 + c] = 0u; }
-            if (i == 0) s_par[0] = 0x7FFFFFFFu;  // root: no parent
-        }
-        __syncthreads();
-    }
+    // The sorted keys are still in LDS behind the counters (inside the future s_box area, clear of s_par): the
+    // binary searches of the tree construction read them there; the boxes are initialised afterwards.
+    const uint32_t* tree_keys = sort_in_lds ? s_keyA : keys;
+    if (lds_refit && tid == 0) s_par[0] = 0x7FFFFFFFu;  // root: no parent
     for (int i = tid; i < n_int; i += BT) {
         int left, right;
-        karras_node(a, keys, F, i, left, right);
+        karras_node(a, tree_keys, F, i, left, right);
         if (lds_refit) {
             if (left < n_int) s_par[left] = (uint32_t)i;
             if (right < n_int) s_par[right] = (uint32_t)i;
         }
+    }
+    if (lds_refit) {
+        __syncthreads();                                 // every search is done with the keys
+        for (int i = tid; i < n_int; i += BT)
+            for (int c = 0; c < 3; ++c) { s_box[6 * i + c] = 0xFFFFFFFFu; s_box[6 * i + 3 + c] = 0u; }
     }
     if (tid == 0) a.parent[F > 1 ? 0 : n_int] = -1;
     __syncthreads();
@@ -532,11 +551,13 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, 
 }
 
 void launch_build_bvh(const BuildArgs& a, hipStream_t stream) {
-    // dynamic LDS: the radix counters (132 KB), or 28 B per inner node for the LDS refit if that is more
+    // dynamic LDS: the radix counters (66 KB) + sort buffers (12 B per face), or 28 B per inner node for the LDS refit if that is more
     // and still fits beside the static arrays (160 KB per CU)
-    size_t lds = ((size_t)RDIG * BT + (size_t)RDIG * BT / 32 + 32) * sizeof(uint32_t);
+    // (radix counters + keys and 16-bit indices of the in-LDS sort)
+    size_t lds = ((size_t)RCNT_WORDS + 3 * (size_t)a.F + 4) * sizeof(uint32_t);
     const size_t refit = 7 * sizeof(uint32_t) * (size_t)(a.F > 1 ? a.F - 1 : 0);
     const size_t lds_max = 160 * 1024 - 1024;
+    if (lds > lds_max) lds = (size_t)RCNT_WORDS * sizeof(uint32_t);      // the sort then goes through global scratch
     if (refit > lds && refit <= lds_max) lds = refit;
     const int split = (refit > lds_max && a.F > 1) ? 1 : 0;      // beyond the LDS refit: chip-wide launches
     if (!split) {
