@@ -308,7 +308,10 @@ int nlos_weighted_l2(nlos_ctx *ctx, const double *transient, const double *data,
 
 /* diagnostics: copy internal scratch of the last render to HOST memory (synchronises the device).
  * what = 0: the visibility cache, uint32 [L, words, F] in Morton-sorted face order (needs
- * keep_visibility or a gradient mode); what = 1: int32 [F] original face id of each sorted slot.
+ * keep_visibility or a gradient mode); what = 1: int32 [F] original face id of each sorted slot;
+ * what = 2: int32 [L] path code of every source in the last single-workgroup grid launch (F <= 5800):
+ * 0 = normal, 0x100 + R = cell lists overflowed and the source was redone on a grid coarsened to R x R,
+ * 1 = redone with the whole CU's LDS.
  * Returns the number of bytes copied (<= max_bytes) or a negative status. */
 int64_t nlos_ctx_debug_read(nlos_ctx *ctx, int what, void *host_out, int64_t max_bytes);
 

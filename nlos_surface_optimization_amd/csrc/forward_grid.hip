@@ -67,6 +67,9 @@ struct BBoxF { float x0, x1, y0, y1; };
 #define NLOS_KSUB 4
 #endif
 constexpr int kSub = NLOS_KSUB;   // sub-cell levels per axis
+#ifndef NLOS_MAX_COARSEN
+#define NLOS_MAX_COARSEN 2
+#endif
 constexpr int kIdxBits = 13;      // single-workgroup grid: 11 depth bits
 constexpr int kIdxBitsTiled = 14; // tiled grid: subsets up to 16383 triangles, 10 depth bits
 #ifndef NLOS_EXACT_ROUND
@@ -200,27 +203,35 @@ __global__ __launch_bounds__(512) void k_tile_bin(ForwardArgs a, int R, int from
 // frame so that all workgroups of a source agree.  Rows and visibility words are combined with atomics
 // (the launcher zeroes them).  A tile whose subset overflows iterates over all faces and uses the BVH
 // query for its own samples; a source whose scene is not strictly in front is handled by tile 0 alone.
-// Workgroups (sources, or tiles) whose cell lists overflow the normal LDS share (two workgroups per CU) flag
-// themselves in a.retry and leave before binning anything; a second launch (`pass` = 1) with one workgroup
-// per CU and ~150 KB of LDS redoes exactly those (grazing views pile thousands of sliver triangles into a
-// few cells / tiles).
-// PASS >= 0 fixes the pass at compile time (the single-workgroup grid: the usually idle retry launch then
-// shows up under its own kernel name in profiles); PASS = -1 takes it from the argument.
-template <int FEAT, int NCM = 0, bool TILED = false, int PASS = -1>
-__global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows_in_lds, int R, int cap, int pass_arg = 0) {
-    const int pass = PASS >= 0 ? PASS : pass_arg;
+// Workgroups (sources, or tiles) whose cell lists overflow the normal LDS share (two workgroups per CU) start
+// over on a coarser grid (grid_body<COARSE = true>, same workgroup, same launch); if even that does not fit they
+// flag themselves in a.retry and leave before binning anything, and a second launch (`pass` = 1) with one
+// workgroup per CU and ~150 KB of LDS redoes exactly those (grazing views pile thousands of sliver triangles
+// into a few cells / tiles).
+// The body of the grid kernel.  COARSE = false: R is the launch constant (the common path; keeping it constant
+// is worth 1.5 % there).  When the cell lists overflow the entry capacity it returns true before binning
+// anything, and the kernel runs the COARSE = true instance for the same source in the same workgroup: that one
+// starts at 3/4 of the resolution and coarsens further (x 3/4, NLOS_MAX_COARSEN times) until the lists fit.
+// Only what still does not fit is flagged for the big-LDS launch.  (Redoing such sources in a separate launch was
+// tried: a few heavy workgroups fill the chip badly -- 4.4 vs 3.2 ms where a third of the sources overflow.)
+template <int FEAT, int NCM, bool TILED, bool COARSE>
+__device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_in_lds, const int R_launch, const int cap, const int pass,
+                                          const int last_pass, uint32_t* s_scan, uint32_t* s_bkt) {
+    constexpr int kCoarsen = COARSE ? NLOS_MAX_COARSEN : 0;
+    // R_launch fixes the LDS layout; the grid actually used (R, R2, ncell) may be coarsened below when the
+    // cell lists of this source do not fit
+    int R = R_launch;
     // dynamic LDS: [ctl: ticket, bad, total, n_live (16 B)][row nbins f64][cells R*R+1 u32]
     //   [union { build: depth bound per 2x2 cells R2*R2 u32, block masks nblk u64 ;
     //            trace: 8 waves x (128 queued pairs + 2 mask words) }][entries cap u32]
     // (the bucketed live-face list lives in global scratch: it is read once per 64-face block)
     extern __shared__ double s_lds[];
     constexpr int IB = TILED ? kIdxBitsTiled : kIdxBits;
-    if (pass == 1 && a.retry[blockIdx.x] == 0) return;     // second launch: only the flagged workgroups
     int* s_ctl = reinterpret_cast<int*>(s_lds);      // 8 ints: ticket, bad, total entries, n_live, tile subset size
     double* s_row = s_lds + 4;
     const int nbins = a.sp.nbins;
-    const int ncell = R * R;
-    const int R2 = (R + 1) >> 1;
+    int ncell = R * R;
+    int R2 = (R + 1) >> 1;
     const int F = a.sc.F;
     const int ntiles = TILED ? a.tiles_x * a.tiles_y : 1;
     const int tile = TILED ? (int)(blockIdx.x % (unsigned)ntiles) : 0;
@@ -239,8 +250,6 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     const bool len_ok = (((R2 * R2 + 1) & ~1) + 2 * mask_blocks) * 4 + ncell <= union_words * 4;
     uint16_t* g_live = a.live + (size_t)blockIdx.x * (TILED ? a.tile_cap : F);
     uint32_t* tl = TILED ? a.tile_list + (size_t)blockIdx.x * a.tile_cap : nullptr;
-    __shared__ uint32_t s_scan[512];
-    __shared__ uint32_t s_bkt[32];                   // live faces per list-length bucket, then the write cursors
 
     const int l = TILED ? (int)(blockIdx.x / (unsigned)ntiles) : (int)blockIdx.x;
     const int tid = threadIdx.x, NT = blockDim.x;
@@ -288,7 +297,20 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
         g.z0 = zr0;
         g.inv_qz = (float)g.zmax / fmaxf(zr1 - zr0, 1e-12f);
     }
+    // a coarser grid over the same frame (fewer, longer cell lists), inside the LDS laid out for R_launch
+    auto set_grid_res = [&](int Rn) {
+        R = Rn; ncell = Rn * Rn; R2 = (Rn + 1) >> 1;
+        g.R = Rn;
+        if (TILED) {
+            g.inv_cw = (float)Rn / (fr.wx * 1.002f / (float)a.tiles_x);
+            g.inv_ch = (float)Rn / (fr.wy * 1.002f / (float)a.tiles_y);
+        } else {
+            g.inv_cw = (float)Rn / (fr.wx * 1.002f);
+            g.inv_ch = (float)Rn / (fr.wy * 1.002f);
+        }
+    };
 
+    if (COARSE) set_grid_res(max(8, (R * 3) >> 2));      // the lists overflowed at R_launch: start one step coarser
     if (rows_in_lds)
         for (int i = tid; i < nbins; i += NT) s_row[i] = 0.0;
     for (int i = tid; i <= ncell; i += NT) s_cell[i] = 0u;
@@ -302,7 +324,7 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     bool ident = true;
     if (TILED) {
         if (!frame_ok) {
-            if (tile != 0) return;                     // tile 0 handles such a source alone (BVH queries)
+            if (tile != 0) return false;               // tile 0 handles such a source alone (BVH queries)
         } else {
             // ---- tile subset, binned by k_tile_bin
             const int nsel = a.tile_count[blockIdx.x];
@@ -367,53 +389,82 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     }
     __syncthreads();
     FWD_STAMP();   // 0: setup + live-face masks + depth bounds
-
-    if (frame_ok && !(TILED && ident)) {
-        // ---- counting pass ---------------------------------------------------------------------------
-        for (int jl = tid; jl < Fl; jl += NT) {
-            const int j = gid(jl);
-            const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
-            const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
-            const uint32_t zn = __float_as_uint(fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f));
-            raster_tri(g, q, [&](int xx, int yy) {
-                if (zn <= s_zc[(yy >> 1) * R2 + (xx >> 1)]) atomicAdd(&s_cell[yy * R + xx], 1u);
-            });
-        }
-    }
-    __syncthreads();
-    FWD_STAMP();   // 1: counting pass
     if (tid == 0) {
         uint32_t run = 0;
         for (int b = 0; b < nblocks; ++b) run += (uint32_t)__popcll(s_mask[b]);
         s_ctl[3] = (int)run;
     }
-    if (frame_ok) {
-        // ---- exclusive scan of the cell counts (each thread owns a contiguous slice) -------------
-        const int per = (ncell + NT - 1) / NT;
-        const int c0 = min(tid * per, ncell), c1 = min(c0 + per, ncell);
-        uint32_t sum = 0;
-        for (int c = c0; c < c1; ++c) sum += s_cell[c];
-        s_scan[tid] = sum;
+    // ---- count + scan; if the cell lists do not fit the entry capacity, coarsen the grid (x 3/4, up to
+    // twice) and count again: fewer cells per triangle, longer lists.  That costs one more depth-bound and
+    // counting pass (~15 % of the kernel) where the alternative is the big-LDS relaunch at half the occupancy.
+    for (int attempt = 0;; ++attempt) {
+        if (attempt > 0) {
+            set_grid_res(max(8, (R * 3) >> 2));
+            for (int i = tid; i <= ncell; i += NT) s_cell[i] = 0u;
+            for (int i = tid; i < R2 * R2; i += NT) s_zc[i] = 0u;
+            if (tid == 0) s_ctl[1] = 0;
+            __syncthreads();
+            for (int b = wave; b < nblocks; b += nwaves) {
+                const int j = (b << 6) + lane;
+                if (j < Fl && ((s_mask[b] >> lane) & 1ull)) {
+                    const int jg = gid(j);
+                    const float4 q0 = a.sc.facerec[4 * jg], q1 = a.sc.facerec[4 * jg + 1], q2 = a.sc.facerec[4 * jg + 2];
+                    const float zfar = fmaxf(fmaxf(q0.z, q1.y), q2.x) - o.z;
+                    const uint32_t zb = __float_as_uint(fmaxf(zfar, 0.0f) * 1.0001f + 1e-30f);
+                    const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
+                    raster_tri(g, q, [&](int xx, int yy) { atomicMax(&s_zc[(yy >> 1) * R2 + (xx >> 1)], zb); });
+                }
+            }
+            __syncthreads();
+        }
+        if (frame_ok && !(TILED && ident)) {
+            // ---- counting pass -----------------------------------------------------------------------
+            for (int jl = tid; jl < Fl; jl += NT) {
+                const int j = gid(jl);
+                const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
+                const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
+                const uint32_t zn = __float_as_uint(fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f));
+                raster_tri(g, q, [&](int xx, int yy) {
+                    if (zn <= s_zc[(yy >> 1) * R2 + (xx >> 1)]) atomicAdd(&s_cell[yy * R + xx], 1u);
+                });
+            }
+        }
         __syncthreads();
-        for (int off = 1; off < NT; off <<= 1) {
-            uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+        if (attempt == 0) FWD_STAMP();   // 1: counting pass
+        if (frame_ok) {
+            // ---- exclusive scan of the cell counts (each thread owns a contiguous slice) ---------
+            const int per = (ncell + NT - 1) / NT;
+            const int c0 = min(tid * per, ncell), c1 = min(c0 + per, ncell);
+            uint32_t sum = 0;
+            for (int c = c0; c < c1; ++c) sum += s_cell[c];
+            s_scan[tid] = sum;
             __syncthreads();
-            s_scan[tid] += v;
-            __syncthreads();
+            for (int off = 1; off < NT; off <<= 1) {
+                uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+                __syncthreads();
+                s_scan[tid] += v;
+                __syncthreads();
+            }
+            uint32_t run = s_scan[tid] - sum;
+            for (int c = c0; c < c1; ++c) {
+                uint32_t n = s_cell[c];
+                s_cell[c] = run;
+                run += n;
+                if (len_ok) s_len8[c] = (uint8_t)min(n, 255u);
+            }
+            if (tid == NT - 1) { s_ctl[2] = (int)s_scan[tid]; if ((int)s_scan[tid] > cap) s_ctl[1] = 1; }
         }
-        uint32_t run = s_scan[tid] - sum;
-        for (int c = c0; c < c1; ++c) {
-            uint32_t n = s_cell[c];
-            s_cell[c] = run;
-            run += n;
-            if (len_ok) s_len8[c] = (uint8_t)min(n, 255u);
-        }
-        if (tid == NT - 1) { s_ctl[2] = (int)s_scan[tid]; if ((int)s_scan[tid] > cap) s_ctl[1] = 1; }
+        __syncthreads();
+        const bool overflow = frame_ok && !(TILED && ident) && s_ctl[1] != 0;
+        if (!overflow || attempt >= kCoarsen || R <= 8) break;
+        __syncthreads();                 // everyone has seen the flag before thread 0 clears it
     }
-    __syncthreads();
-    if (pass == 0 && a.retry && frame_ok && !(TILED && ident) && s_ctl[1] != 0) {
-        if (tid == 0) a.retry[blockIdx.x] = 1;      // cell lists overflow: redo with the big-LDS launch
-        return;
+    if (frame_ok && !(TILED && ident) && s_ctl[1] != 0) {
+        if (!COARSE && R > 8) return true;                     // cell lists overflow: once more, coarser, right here
+        if (pass < last_pass && a.retry) {
+            if (tid == 0) a.retry[blockIdx.x] = pass + 1;      // still too many entries: redo in the big-LDS launch
+            return false;
+        }
     }
     FWD_STAMP();   // 2: scans
     // ---- fill pass: s_cell[c] is the write cursor, afterwards the END of cell c ------------------
@@ -766,6 +817,9 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
     }
 #endif
     FWD_STAMP();   // 5: sample + trace + histogram
+    // diagnostics (nlos_ctx_debug_read what = 2): the coarsened resolution this workgroup ended up with; the
+    // big-LDS launch only looks for the value 1
+    if (COARSE && a.retry && tid == 0) a.retry[blockIdx.x] = 0x100 + R;
     if (rows_in_lds && grow) {
         __syncthreads();
         if (!TILED) {
@@ -774,6 +828,22 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
             for (int i = tid; i < nbins; i += NT)
                 if (s_row[i] != 0.0) unsafeAtomicAdd(&grow[i], s_row[i]);     // one partial row per tile
         }
+    }
+    return false;
+}
+
+// PASS >= 0 fixes the pass at compile time (the single-workgroup grid: the usually idle big-LDS launch then
+// shows up under its own kernel name in profiles); PASS = -1 takes it from the argument.
+template <int FEAT, int NCM = 0, bool TILED = false, int PASS = -1>
+__global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows_in_lds, int R, int cap, int pass_arg = 0,
+                                                         int last_pass = 1) {
+    __shared__ uint32_t s_scan[512];
+    __shared__ uint32_t s_bkt[32];                   // live faces per list-length bucket, then the write cursors
+    const int pass = PASS >= 0 ? PASS : pass_arg;
+    if (pass >= 1 && a.retry[blockIdx.x] != pass) return;  // second launch: only the workgroups flagged for it
+    if (grid_body<FEAT, NCM, TILED, false>(a, rows_in_lds, R, cap, pass, last_pass, s_scan, s_bkt)) {
+        __syncthreads();
+        grid_body<FEAT, NCM, TILED, true>(a, rows_in_lds, R, cap, pass, last_pass, s_scan, s_bkt);
     }
 }
 
@@ -806,11 +876,12 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
     if (a.retry) (void)hipMemsetAsync(a.retry, 0, sizeof(int) * (size_t)a.src.L, stream);
     // kScan slots of slack: the walk reads kScan entries per trip and may touch the slots after the last list
+    const int last_pass = a.retry ? 1 : 0;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, false, 0>), dim3(a.src.L), dim3(512), lds, stream, a, rows_in_lds, R,
-                       (int)cap - kScan, 0);
-    if (a.retry)      // sources whose cell lists overflowed: once more with the whole CU's LDS
+                       (int)cap - kScan, 0, last_pass);
+    if (a.retry)      // sources whose cell lists overflowed even on the coarsened grid: once more with the whole CU's LDS
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, false, 1>), dim3(a.src.L), dim3(512), lds_big, stream, a,
-                           rows_in_lds, R, (int)((lds_big - fixed) / 4) - kScan, 1);
+                           rows_in_lds, R, (int)((lds_big - fixed) / 4) - kScan, 1, last_pass);
     return true;
 }
 
@@ -845,9 +916,9 @@ bool forward_tiled_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t str
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, true>), dim3((unsigned)nwg), dim3(512), lds, stream, a, rows_in_lds, R,
-                       (int)cap - kScan, 0);
+                       (int)cap - kScan, 0, 1);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, true>), dim3((unsigned)nwg), dim3(512), lds_big, stream, a, rows_in_lds,
-                       R, (int)cap_big - kScan, 1);
+                       R, (int)cap_big - kScan, 1, 1);
     return true;
 }
 

@@ -547,8 +547,9 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h, c->status.p, sizeof(h), hipMemcpyDeviceToHost));
         double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5]);
-        std::fprintf(stderr, "[fwd stamps] setup %.1f%% count %.1f%% scan %.1f%% fill %.1f%% live-buckets %.1f%% trace %.1f%%\n",
-                     100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot);
+        std::fprintf(stderr, "[fwd stamps] setup %.1f%% count %.1f%% scan %.1f%% fill %.1f%% live-buckets %.1f%% trace %.1f%% | Mcycles per source %.3f\n",
+                     100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot,
+                     tot / 1e6 / (double)(L > 0 ? L : 1));
         double tt = (double)(h[14] + h[15] + h[16] + h[17]);
         std::fprintf(stderr, "[fwd trace shares] generate %.1f%% filter-scan %.1f%% exact-rounds %.1f%% histogram+vis %.1f%%\n",
                      100 * h[14] / tt, 100 * h[15] / tt, 100 * h[16] / tt, 100 * h[17] / tt);
@@ -692,11 +693,14 @@ int nlos_intersect(nlos_ctx* c, const float* origins, const float* dirs, int n_r
 int64_t nlos_ctx_debug_read(nlos_ctx* c, int what, void* host_out, int64_t max_bytes) {
     if (!c || !host_out || max_bytes < 0) return -(int64_t)fail(NLOS_ERR_ARG, "nlos_ctx_debug_read: bad arguments");
     DeviceGuard guard(c->device);
-    const DevBuf* b = what == 0 ? &c->vis : (what == 1 ? &c->face_id : nullptr);
+    // what = 2: per-workgroup path codes of the last single-workgroup grid launch (0 normal, 1 redone with the
+    // whole CU's LDS, 0x100 + R: redone on a grid coarsened to R x R)
+    const DevBuf* b = what == 0 ? &c->vis : (what == 1 ? &c->face_id : (what == 2 ? &c->tile_count : nullptr));
     if (!b || !b->p) return -(int64_t)fail(NLOS_ERR_ARG, "nlos_ctx_debug_read: nothing to read");
     size_t n = 0;
     if (what == 0) n = sizeof(uint32_t) * (size_t)c->vis_key.L * (size_t)((c->vis_key.spt + 31) / 32) * (size_t)c->vis_key.F;
-    else n = sizeof(int) * (size_t)c->built_F;
+    else if (what == 1) n = sizeof(int) * (size_t)c->built_F;
+    else n = (size_t)max_bytes;
     if (n > (size_t)max_bytes) n = (size_t)max_bytes;
     if (n > b->cap) n = b->cap;
     hipError_t e = hipDeviceSynchronize();

@@ -240,6 +240,16 @@ class TransientRenderer:
                 raise _lib.NlosError("nlos_ctx_debug_read(%d) returned %d, expected %d" % (what, n, arr.nbytes))
         return vis, fid
 
+    def debug_grid_paths(self, L):
+        """Diagnostics: int32 [L] path code per source of the last single-workgroup grid launch (0 normal,
+        0x100 + R coarsened to R x R after a cell-list overflow, 1 redone with the whole CU's LDS)."""
+        import numpy as np
+        codes = np.zeros(L, np.int32)
+        n = self._lib.nlos_ctx_debug_read(self._h, 2, codes.ctypes.data_as(ctypes.c_void_p), codes.nbytes)
+        if n != codes.nbytes:
+            raise _lib.NlosError("nlos_ctx_debug_read(2) returned %d, expected %d" % (n, codes.nbytes))
+        return codes
+
     def create_weighting_function(self, data, gamma=1.0):
         """exp_bunny/rendering.py:208-217 on a device tensor: (data/max + 0.1)^gamma, rescaled to sum to data.numel()."""
         _want(data, torch.float64, "data", 2)

@@ -3,7 +3,7 @@
 set -e
 cd "$GRAFT_REPO_ROOT"
 cp -r nlos_surface_optimization_amd /tmp/nlos_stamped && cp -r include /tmp/include
-make -s -C /tmp/nlos_stamped/csrc clean >/dev/null; make -s -C /tmp/nlos_stamped/csrc -j4 EXTRA="-DNLOS_BUILD_STAMPS -DNLOS_FWD_STAMPS"
+make -s -C /tmp/nlos_stamped/csrc clean >/dev/null; make -s -C /tmp/nlos_stamped/csrc -j4 EXTRA="-DNLOS_BUILD_STAMPS -DNLOS_FWD_STAMPS $NLOS_STAMP_EXTRA"
 cd /tmp && ln -sf "$GRAFT_REPO_ROOT/tests" tests 2>/dev/null || true
 python3 - <<'PY'
 import sys, importlib.util, numpy as np, torch
