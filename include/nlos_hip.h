@@ -245,7 +245,7 @@ typedef struct nlos_render_args {
                                    previous render on this ctx (same mesh, sources, samples, seed) */
     int32_t force_bvh;          /* 1: occlusion by BVH traversal only (default 0: per-source perspective
                                    grid in LDS, tiled over several workgroups per source for meshes beyond
-                                   5.8 k faces; identical results).  2 (diagnostic): tiled grid with a tiny
+                                   6.2 k faces; identical results).  2 (diagnostic): tiled grid with a tiny
                                    per-tile capacity, to exercise the tiles' overflow fallback */
     /* non-confocal pairs (the reference has only Python prototypes of it:
      * transient_rendering_python/rendering.py:8-93, mesh_optimization/rendering.py:739-797).
@@ -309,7 +309,7 @@ int nlos_weighted_l2(nlos_ctx *ctx, const double *transient, const double *data,
 /* diagnostics: copy internal scratch of the last render to HOST memory (synchronises the device).
  * what = 0: the visibility cache, uint32 [L, words, F] in Morton-sorted face order (needs
  * keep_visibility or a gradient mode); what = 1: int32 [F] original face id of each sorted slot;
- * what = 2: int32 [L] path code of every source in the last single-workgroup grid launch (F <= 5800):
+ * what = 2: int32 [L] path code of every source in the last single-workgroup grid launch (F <= 6200):
  * 0 = normal, 0x100 + R = cell lists overflowed and the source was redone on a grid coarsened to R x R,
  * 1 = redone with the whole CU's LDS.
  * Returns the number of bytes copied (<= max_bytes) or a negative status. */

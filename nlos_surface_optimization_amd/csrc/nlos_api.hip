@@ -456,7 +456,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.tile_count = nullptr;
     fa.retry = nullptr;
     fa.tiles_x = fa.tiles_y = fa.tile_cap = 0;
-    static const int tile_threshold = [] { const char* e = std::getenv("NLOS_TILE_THRESHOLD"); return e ? std::atoi(e) : 5800; }();
+    static const int tile_threshold = [] { const char* e = std::getenv("NLOS_TILE_THRESHOLD"); return e ? std::atoi(e) : 6200; }();
     if (nF <= tile_threshold && a->force_bvh != 1) {
         rc = c->live.ensure(sizeof(uint16_t) * (size_t)(L > 0 ? L : 1) * nF + 16);
         if (!rc) rc = c->tile_count.ensure(sizeof(int) * (size_t)(L > 0 ? L : 1) + 16);

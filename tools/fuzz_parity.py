@@ -103,7 +103,7 @@ def main():
         tv, tf_, to, tn = (torch.from_numpy(x).to(dev) for x in (v, f, o, nrm))
         tvn = None if vn is None else torch.from_numpy(vn).to(dev)
         errs = []
-        for fb in (0, 1) + ((2,) if F > 5800 else ()):
+        for fb in (0, 1) + ((2,) if F > 6200 else ()):
             t, _ = r.render_transient(to, tn, tv, tf_, ns, lb, ub, res, vertex_normal=tvn, force_bvh=fb)
             errs.append(rel_l2(t.cpu().numpy(), t_ref))
         et = max(errs)
@@ -135,7 +135,7 @@ def main():
                 en = max(en, rel_l2(t.cpu().numpy(), tn_ref))
             et = max(et, en)
         ex = 0.0
-        if rs.rand() < 0.3 and t_ref.sum() > 0 and F <= 5800:
+        if rs.rand() < 0.3 and t_ref.sum() > 0 and F <= 6200:
             # other rows on the same scene: GGX branch, SPAD jitter gradient, v1 driver, per-face intensity
             alpha = float(rs.uniform(0.05, 0.9))
             tg_ref, _ = orc.render_transient(o, nrm, v, f, ns, lb, ub, res, ggx_alpha=alpha, vnormal=vn, accel=1, seed=case)
@@ -166,7 +166,7 @@ def main():
             bad += 1
         worst_t, worst_g = max(worst_t, et), max(worst_g, eg)
         print("case %3d F=%6d L=%d spt=%2d T=%4d vn=%d sum=%.3e  transient %.2e (grid/bvh%s)  gradient %.2e  nc %.2e  ggx/jitter/intensity %.2e %s" % (
-            case, F, L, spt, T, int(use_vn), t_ref.sum(), et, "/ovf" if F > 5800 else "", eg, en, ex, "" if ok else "  <-- MISMATCH"),
+            case, F, L, spt, T, int(use_vn), t_ref.sum(), et, "/ovf" if F > 6200 else "", eg, en, ex, "" if ok else "  <-- MISMATCH"),
             flush=True)
     print("cases with a differing sample (grazing-occluder candidates, see tools/fuzz_case.py): %d" % grazing)
     print("worst transient %.3e, worst gradient %.3e, mismatches %d / %d" % (worst_t, worst_g, bad, n_cases))
