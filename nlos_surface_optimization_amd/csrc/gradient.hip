@@ -8,6 +8,8 @@
 // No ray is traced here: pass 1 left one bit per accepted sample.
 #include "render_common.h"
 
+#include <cstdlib>
+
 namespace nlos {
 namespace {
 
@@ -15,8 +17,10 @@ namespace {
 #define NLOS_GRAD_NT 512
 #define NLOS_GRAD_WPS 4
 #endif
-template <int FEAT, int MODE, bool NC = false>
-__global__ __launch_bounds__(NLOS_GRAD_NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) {
+// NT = 1024: one workgroup per CU with the same sixteen waves, for meshes whose 3V-double accumulator leaves no
+// room for two workgroups of 512 (V > ~2600)
+template <int FEAT, int MODE, bool NC = false, int NT = NLOS_GRAD_NT>
+__global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) {
     extern __shared__ double s_mem[];       // [ticket (8 B)][diff row T][tap tables 3K+2][grad 3V][masks][bases][live]
     int* s_next = reinterpret_cast<int*>(s_mem);
     const int T = a.sp.nbins;
@@ -425,16 +429,30 @@ bool gradient_fm_launch(const GradientArgs& a, hipStream_t stream) {
 }
 
 template <int FEAT, int MODE>
-void gradient_launch2(const GradientArgs& a, int grid, size_t lds, hipStream_t stream) {
+void gradient_launch2(const GradientArgs& a, int grid, size_t lds, hipStream_t stream, bool wide = false) {
+    if constexpr (MODE == 0) {
+        if (wide) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, 0, false, 1024>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, 0, false, 1024>), dim3(grid), dim3(1024), lds, stream, a);
+            return;
+        }
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, MODE>), dim3(grid), dim3(NLOS_GRAD_NT), lds, stream, a);
 }
 
 template <int FEAT>
-void gradient_launch(const GradientArgs& a, int grid, size_t lds, hipStream_t stream) {
+void gradient_launch(const GradientArgs& a, int grid, size_t lds, hipStream_t stream, bool wide) {
     if (a.src.sensor) {
         if constexpr ((FEAT & FEAT_GGX) == 0) {
+            if (wide) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, 0, true, 1024>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, 0, true, 1024>), dim3(grid), dim3(1024), lds, stream, a);
+                return;
+            }
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, 0, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, 0, true>), dim3(grid), dim3(NLOS_GRAD_NT), lds, stream, a);
@@ -442,7 +460,7 @@ void gradient_launch(const GradientArgs& a, int grid, size_t lds, hipStream_t st
         return;
     }
     switch (a.mode) {
-        case 0: gradient_launch2<FEAT, 0>(a, grid, lds, stream); break;
+        case 0: gradient_launch2<FEAT, 0>(a, grid, lds, stream, wide); break;
         case 1: gradient_launch2<FEAT, 1>(a, grid, lds, stream); break;
         case 2: gradient_launch2<FEAT, 2>(a, grid, lds, stream); break;
         case 4:
@@ -487,15 +505,18 @@ void launch_gradient(const GradientArgs& a_in, hipStream_t stream) {
     if (per_cu < 1) per_cu = 1;
     int grid = 256 * per_cu;
     if (grid > a.src.L) grid = a.src.L;
+    // a single workgroup per CU: give it the sixteen waves two workgroups would have had
+    static const int wide_ok = [] { const char* e = std::getenv("NLOS_GRAD_WIDE"); return e ? std::atoi(e) : 1; }();
+    const bool wide = per_cu == 1 && a.mode == 0 && wide_ok;
     switch (feat_of(a.sc, a.sp)) {
-        case 0: gradient_launch<0>(a, grid, lds, stream); break;
-        case 1: gradient_launch<1>(a, grid, lds, stream); break;
-        case 2: gradient_launch<2>(a, grid, lds, stream); break;
-        case 3: gradient_launch<3>(a, grid, lds, stream); break;
-        case 4: gradient_launch<4>(a, grid, lds, stream); break;
-        case 5: gradient_launch<5>(a, grid, lds, stream); break;
-        case 6: gradient_launch<6>(a, grid, lds, stream); break;
-        default: gradient_launch<7>(a, grid, lds, stream); break;
+        case 0: gradient_launch<0>(a, grid, lds, stream, wide); break;
+        case 1: gradient_launch<1>(a, grid, lds, stream, wide); break;
+        case 2: gradient_launch<2>(a, grid, lds, stream, wide); break;
+        case 3: gradient_launch<3>(a, grid, lds, stream, wide); break;
+        case 4: gradient_launch<4>(a, grid, lds, stream, wide); break;
+        case 5: gradient_launch<5>(a, grid, lds, stream, wide); break;
+        case 6: gradient_launch<6>(a, grid, lds, stream, wide); break;
+        default: gradient_launch<7>(a, grid, lds, stream, wide); break;
     }
 }
 

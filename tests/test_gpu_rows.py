@@ -374,6 +374,36 @@ def test_cell_list_overflow_is_redone_on_a_coarser_grid(bunny, orc):
     assert (r.debug_grid_paths(origin.shape[0]) == 0).all()
 
 
+def test_mid_size_mesh_single_wide_gradient_workgroup(bunny, orc):
+    """5.7 k irregular faces (decimated from the subdivided bunny), V ~ 2850: the 3V-double accumulator leaves room
+    for one gradient workgroup per CU, which then runs with 1024 threads; the forward grid is near its entry
+    capacity (coarsened for some sources).  Confocal and non-confocal gradients vs the oracle."""
+    import torch
+    from nlos_surface_optimization_amd import device as nd, mesh_io
+    v0, f0 = bunny
+    v1, f1 = mesh_io.subdivide(v0, f0, 1)
+    v, f = mesh_io.decimate_to(v1, f1, 5790)
+    v, f = np.ascontiguousarray(v, np.float32), np.ascontiguousarray(f, np.int32)
+    assert 5300 < f.shape[0] <= 6200 and v.shape[0] > 2650
+    origin, normal = grid_sources(3, 0.2)
+    ns = 2 * f.shape[0]
+    t_o, _ = orc.render_transient(origin, normal, v, f, ns, LB, UB, RES, accel=1, seed=2)
+    data = t_o * (1 + 0.2 * np.random.RandomState(4).standard_normal(t_o.shape))
+    w = np.ones_like(data)
+    _, g_o, _ = orc.render_gradient(origin, normal, v, f, ns, LB, UB, RES, data, w, accel=1, seed=2)
+    dev = torch.device("cuda", 0)
+    r = nd.TransientRenderer(dev, seed=2)
+    dv = lambda x: torch.from_numpy(x).to(dev)
+    tr, grad, _ = r.render_gradient(dv(origin), dv(normal), dv(v), dv(f), ns, LB, UB, RES, data=dv(data), weight=dv(w))
+    assert rel_l2(tr.cpu().numpy(), t_o) <= 1e-5 and rel_l2(grad.cpu().numpy(), g_o) <= 1e-4
+    b = origin.copy()
+    b[:, 0] += 0.04
+    t2, g2, _ = orc.render_nonconfocal(origin, normal, b, normal, v, f, ns, LB, UB, RES, data=data, weight=w, accel=1, seed=2)
+    tr2, grad2, _ = r.render_gradient(dv(origin), dv(normal), dv(v), dv(f), ns, LB, UB, RES, data=dv(data), weight=dv(w),
+                                      sensor=dv(b), sensor_normal=dv(normal))
+    assert rel_l2(tr2.cpu().numpy(), t2) <= 1e-5 and rel_l2(grad2.cpu().numpy(), g2) <= 1e-4
+
+
 # ------------------------------------------------------------------ row N: non-confocal pairs
 def _nc_pairs(n=3):
     a, na = grid_sources(n, 0.2)
