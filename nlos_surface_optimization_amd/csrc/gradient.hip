@@ -285,7 +285,12 @@ __global__ __launch_bounds__(kFmThreads) void k_gradient_fm(GradientArgs a, int 
     uint16_t* s_list = reinterpret_cast<uint16_t*>(s_p1 + K + 1);
     int* s_cnt = reinterpret_cast<int*>(s_list + kFmBatch * kFmChunk);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int f0 = blockIdx.x * kFmChunk, nf = min(kFmChunk, F - f0);
+    // A chunk is kFmChunk / 64 blocks of 64 consecutive faces taken round-robin over the Morton order (block
+    // b of the chunk = 64-face block b * gridDim.x + blockIdx.x): every chunk then holds a similar mix of faces
+    // that see the wall and faces that do not -- consecutive chunks differ by 100x in accepted samples and the
+    // heavy ones set the kernel time (1.45 -> see DESIGN at F = 20 k).  64-face granularity keeps the visibility
+    // words and the face records coalesced.
+    auto face_of = [&](int jl) -> int { return (((jl >> 6) * (int)gridDim.x + (int)blockIdx.x) << 6) + (jl & 63); };
     const int l0 = blockIdx.y * src_per_group, l1 = min(l0 + src_per_group, a.src.L);
     const int spt = a.sp.spt;
     const int Ltot = a.src.total_sources > 0 ? a.src.total_sources : a.src.L;
@@ -306,8 +311,8 @@ __global__ __launch_bounds__(kFmThreads) void k_gradient_fm(GradientArgs a, int 
         for (int it = tid; it < nb * kFmChunk; it += kFmThreads) {
             const int bl = it / kFmChunk, jl = it - bl * kFmChunk;
             uint32_t any = 0;
-            if (jl < nf) {
-                const uint32_t* visp = a.vis + ((size_t)(lb0 + bl) * a.vis_words) * F + f0 + jl;
+            if (face_of(jl) < F) {
+                const uint32_t* visp = a.vis + ((size_t)(lb0 + bl) * a.vis_words) * F + face_of(jl);
                 for (int wi = 0; wi < a.vis_words; ++wi) any |= visp[(size_t)wi * F];
             }
             const unsigned long long m = __ballot(any != 0u);
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(kFmThreads) void k_gradient_fm(GradientArgs a, int 
         for (int it = tid; it < n_items; it += kFmThreads) {
             const int code = s_list[it];
             const int bl = code >> 12, jl = code & 0xFFF;
-            const int l = lb0 + bl, j = f0 + jl;
+            const int l = lb0 + bl, j = face_of(jl);
             const double* s_diff = s_rows + bl * T;
             const Face f = load_face(a.sc.facerec, j);
             const Tri tr = load_tri(a.sc.tris, j);
@@ -384,8 +389,9 @@ __global__ __launch_bounds__(kFmThreads) void k_gradient_fm(GradientArgs a, int 
     }
     __syncthreads();
     // one pass over the chunk: scale and scatter to the vertices
-    for (int jl = tid; jl < nf; jl += kFmThreads) {
-        const Face f = load_face(a.sc.facerec, f0 + jl);
+    for (int jl = tid; jl < kFmChunk; jl += kFmThreads) {
+        if (face_of(jl) >= F) continue;
+        const Face f = load_face(a.sc.facerec, face_of(jl));
         if (f.degenerate) continue;
         const double sc = (double)f.area / (double)spt / (double)Ltot;
         const int vi[3] = {f.i0, f.i1, f.i2};
