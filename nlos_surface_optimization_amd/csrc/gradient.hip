@@ -271,10 +271,16 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
 // the end.  Per batch of kFmBatch sources it loads the residual rows, compacts the (source, face) items
 // with accepted samples into an LDS list (ballot + one LDS counter) and hands them to the lanes densely.
 // Same per-sample arithmetic as k_gradient<FEAT, 0>; only the fp64 summation order differs.
-constexpr int kFmChunk = 512, kFmBatch = 4, kFmThreads = 256;
+#ifndef NLOS_FM_CHUNK
+#define NLOS_FM_CHUNK 512
+#define NLOS_FM_BATCH 4
+#define NLOS_FM_THREADS 256
+#define NLOS_FM_WPS 1
+#endif
+constexpr int kFmChunk = NLOS_FM_CHUNK, kFmBatch = NLOS_FM_BATCH, kFmThreads = NLOS_FM_THREADS;
 
 template <int FEAT, bool NC = false>
-__global__ __launch_bounds__(kFmThreads) void k_gradient_fm(GradientArgs a, int src_per_group) {
+__global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(GradientArgs a, int src_per_group) {
     extern __shared__ double s_fm[];      // [acc 9*CHUNK][rows BATCH*T][delta K][p0 K+1][p1 K+1][list BATCH*CHUNK u16][ctl]
     const int T = a.sp.nbins, K = a.K, F = a.sc.F;
     double* s_acc = s_fm;
