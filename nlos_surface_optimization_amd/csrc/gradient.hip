@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
             const int l = lb0 + bl, j = face_of(jl);
             const double* s_diff = s_rows + bl * T;
             const Face f = load_face(a.sc.facerec, j);
-            const Tri tr = load_tri(a.sc.tris, j);
+            const Tri tr = make_tri(f.p0, f.p1, f.p2);      // what the builder stored (same function, same bits): no 48-B gather
             const V3 o = ld3(a.src.origin + 3 * (size_t)l);
             const V3 on = ld3(a.src.normal + 3 * (size_t)l);
             const uint64_t kbase = ((uint64_t)(a.src.source_offset + l) * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
