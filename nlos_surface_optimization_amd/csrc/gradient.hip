@@ -291,12 +291,16 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
     uint16_t* s_list = reinterpret_cast<uint16_t*>(s_p1 + K + 1);
     int* s_cnt = reinterpret_cast<int*>(s_list + kFmBatch * kFmChunk);
     const int tid = threadIdx.x, lane = tid & 63;
-    // A chunk is kFmChunk / 64 blocks of 64 consecutive faces taken round-robin over the Morton order (block
-    // b of the chunk = 64-face block b * gridDim.x + blockIdx.x): every chunk then holds a similar mix of faces
+    // A chunk is kFmChunk / 8 blocks of 8 consecutive faces taken round-robin over the Morton order (block b
+    // of the chunk = 8-face block b * gridDim.x + blockIdx.x): every chunk then holds a similar mix of faces
     // that see the wall and faces that do not -- consecutive chunks differ by 100x in accepted samples and the
-    // heavy ones set the kernel time (1.45 -> see DESIGN at F = 20 k).  64-face granularity keeps the visibility
-    // words and the face records coalesced.
-    auto face_of = [&](int jl) -> int { return (((jl >> 6) * (int)gridDim.x + (int)blockIdx.x) << 6) + (jl & 63); };
+    // heavy ones set the kernel time (512 consecutive faces: 1.45 ms at F = 20 k; 64-face blocks 1.11; 8-face
+    // blocks 1.02; finer changes nothing).  Eight faces are one 32-byte piece of a visibility row.
+#ifndef NLOS_FM_BLK_SHIFT
+#define NLOS_FM_BLK_SHIFT 3
+#endif
+    constexpr int kBs = NLOS_FM_BLK_SHIFT;
+    auto face_of = [&](int jl) -> int { return (((jl >> kBs) * (int)gridDim.x + (int)blockIdx.x) << kBs) + (jl & ((1 << kBs) - 1)); };
     const int l0 = blockIdx.y * src_per_group, l1 = min(l0 + src_per_group, a.src.L);
     const int spt = a.sp.spt;
     const int Ltot = a.src.total_sources > 0 ? a.src.total_sources : a.src.L;
