@@ -355,12 +355,28 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     // a ray of this source can end.
     auto face_dark = [&](const Face& f) -> bool {
         bool dark = f.degenerate;
-        if (!dark && !(FEAT & FEAT_VN) && a.sp.clamp) {
-            const float dist = dot(f.fn, o - f.p0);
+        if (!dark && a.sp.clamp) {
             const float sc = fabsf(o.x - f.p0.x) + fabsf(o.y - f.p0.y) + fabsf(o.z - f.p0.z);
-            const bool behind = dist < -1e-4f * sc;
             const bool infront = dot(on, f.p0 - o) > 1e-4f * sc && dot(on, f.p1 - o) > 1e-4f * sc &&
                                  dot(on, f.p2 - o) > 1e-4f * sc;
+            bool behind;
+            if (!(FEAT & FEAT_VN)) {
+                behind = dot(f.fn, o - f.p0) < -1e-4f * sc;
+            } else {
+                // interpolated normals: n . (o - p) = sum_i b_i n_i . (o - p) is linear in p for each n_i, so it is
+                // negative on the whole face if it is at the three corners, for all three vertex normals
+                // (b_i >= 0 up to the rounding of the hit's barycentrics, 1e-7 against the 1e-4 margin)
+                const float* vn = a.sc.vertex_normal;
+                const V3 n3[3] = {ld3(vn + 3 * (size_t)f.i0), ld3(vn + 3 * (size_t)f.i1), ld3(vn + 3 * (size_t)f.i2)};
+                const V3 d0 = o - f.p0, d1 = o - f.p1, d2 = o - f.p2;
+                const float sc2 = fmaxf(sc, fmaxf(fabsf(d1.x) + fabsf(d1.y) + fabsf(d1.z), fabsf(d2.x) + fabsf(d2.y) + fabsf(d2.z)));
+                behind = true;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float m = -1e-4f * sc2 * (fabsf(n3[i].x) + fabsf(n3[i].y) + fabsf(n3[i].z));
+                    behind = behind && dot(n3[i], d0) < m && dot(n3[i], d1) < m && dot(n3[i], d2) < m;
+                }
+            }
             dark = behind && infront;
         }
         return dark;

@@ -371,6 +371,9 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     if (!(a->resolution > 0.0f) || !(a->upper_bound > a->lower_bound) )
         if (a->mode != NLOS_MODE_INTENSITY) return fail(NLOS_ERR_ARG, "nlos_render: need resolution > 0 and upper_bound > lower_bound");
     if (a->refine_scale < 1 || a->sigma_bin < 1) return fail(NLOS_ERR_ARG, "nlos_render: refine_scale and sigma_bin must be >= 1");
+    // the temporal kernel's taps are staged in LDS by the smoothing and gradient kernels
+    if ((long long)4 * a->refine_scale * a->sigma_bin + a->refine_scale > 2048 || a->jitter_length > 2048)
+        return fail(NLOS_ERR_ARG, "nlos_render: temporal kernel longer than 2048 taps (4 * refine_scale * sigma_bin + 1, or jitter_length)");
     const int mode = a->mode;
     const bool needs_grad = mode == NLOS_MODE_GRADIENT || mode == NLOS_MODE_GRAD_ALBEDO || mode == NLOS_MODE_GRAD_ALPHA ||
                             mode == NLOS_MODE_GRADIENT_V1;

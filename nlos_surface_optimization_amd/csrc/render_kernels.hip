@@ -28,23 +28,36 @@ namespace nlos {
 namespace {
 
 // --------------------------------------------------------------------- smooth
-__global__ __launch_bounds__(256) void k_smooth(SmoothArgs a) {
+// transient[t] = sum_q y[t R + q + half] with y = fine (*) kernel (full convolution), regrouped per input
+// sample: transient[t] = sum_i fine[i] W[t R + half - i],  W[m] = sum_{q < R} kernel[m + q] -- K + R - 1
+// multiply-adds per output bin instead of K R (201 x 10 at sigma_bin = 5: 2.46 -> see DESIGN ms for 1024 rows),
+// the row and W staged in LDS.  Same terms as the literal double loop, summed in another order (fp64).
+__global__ __launch_bounds__(256) void k_smooth(SmoothArgs a, int row_in_lds) {
+    extern __shared__ double s_sm[];          // [W: K + R - 1][fine row: T R when it fits]
     const int l = blockIdx.x;
     const int R = a.refine, K = a.K, half = a.offset;
     const int rb = a.T * R;
-    const double* fine = a.fine + (size_t)l * rb;
-    for (int t = threadIdx.x; t < a.T; t += blockDim.x) {
-        double acc = 0.0;
+    const int nw = K + R - 1;
+    double* s_w = s_sm;
+    double* s_f = s_sm + nw;
+    const double* gfine = a.fine + (size_t)l * rb;
+    for (int m = threadIdx.x; m < nw; m += blockDim.x) {
+        double w = 0.0;
         for (int q = 0; q < R; ++q) {
-            // y[b + half] with y = full convolution of fine (*) kernel
-            int c = t * R + q + half;
-            double y = 0.0;
-            for (int j = 0; j < K; ++j) {
-                int i = c - j;
-                if (i >= 0 && i < rb) y += fine[i] * a.kernel[j];
-            }
-            acc += y;
+            const int j = m - (R - 1) + q;
+            if (j >= 0 && j < K) w += a.kernel[j];
         }
+        s_w[m] = w;                           // W[m - (R - 1)]
+    }
+    if (row_in_lds)
+        for (int i = threadIdx.x; i < rb; i += blockDim.x) s_f[i] = gfine[i];
+    __syncthreads();
+    const double* fine = row_in_lds ? s_f : gfine;
+    for (int t = threadIdx.x; t < a.T; t += blockDim.x) {
+        const int c = t * R + half;
+        const int i0 = max(0, c - (K - 1)), i1 = min(rb - 1, c + R - 1);
+        double acc = 0.0;
+        for (int i = i0; i <= i1; ++i) acc += fine[i] * s_w[c - i + R - 1];
         a.transient[(size_t)l * a.T + t] = acc;
     }
 }
@@ -139,7 +152,12 @@ void launch_forward(const ForwardArgs& a, hipStream_t stream) {
 
 void launch_smooth(const SmoothArgs& a, hipStream_t stream) {
     if (a.L <= 0) return;
-    hipLaunchKernelGGL(k_smooth, dim3(a.L), dim3(256), 0, stream, a);
+    const size_t wbytes = ((size_t)a.K + a.refine - 1) * sizeof(double);
+    const size_t row = (size_t)a.T * a.refine * sizeof(double);
+    const int row_in_lds = wbytes + row <= 64 * 1024 ? 1 : 0;       // two or more workgroups per CU; W alone is <= 16 KB (API limit of 2048 taps)
+    const size_t lds = wbytes + (row_in_lds ? row : 0);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_smooth, dim3(a.L), dim3(256), lds, stream, a, row_in_lds);
 }
 
 void launch_residual(const ResidualArgs& a, hipStream_t stream) {
