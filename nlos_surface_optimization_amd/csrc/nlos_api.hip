@@ -122,24 +122,28 @@ int get_default_ctx(nlos_ctx** out) {
 // Gaussian taps of the gradient pass, computed exactly as the reference does
 // (smoothed_transient/transient_and_gradient.cpp:537-547, :973-974): K =
 // 4*refine*sigma_bin+1, sigma = res*sigma_bin/2.355 (float*int, then double),
-// delta_i evaluated in float.  Layout: [w(K) | delta(K) | g(K) | P0(K+1) | P1(K+1)] with the
-// prefix sums the grouped-tap gradient kernel uses.
+// delta_i evaluated in float.  Layout: [w(K) | delta(K) | g(K) | P0(K+1) | P1(K+1) | PW(K+1)] with the
+// prefix sums the grouped-tap gradient kernels use (P0, P1 over the float-rounded weights of the vertex
+// gradient; PW over the double weights of the scalar gradients).
 void host_prefix(std::vector<double>& t, int K) {
-    double p0 = 0.0, p1 = 0.0;
+    double p0 = 0.0, p1 = 0.0, pw = 0.0;
     t[3 * (size_t)K] = 0.0;
     t[4 * (size_t)K + 1] = 0.0;
+    t[5 * (size_t)K + 2] = 0.0;
     for (int i = 0; i < K; ++i) {
         double wf = (double)(float)t[i];
         p0 += wf;
         p1 += t[2 * (size_t)K + i] * wf;
+        pw += t[i];
         t[3 * (size_t)K + 1 + i] = p0;
         t[4 * (size_t)K + 2 + i] = p1;
+        t[5 * (size_t)K + 3 + i] = pw;
     }
 }
 
 void host_taps(int refine, int sigma_bin, float res, std::vector<double>& t) {
     const int K = 4 * refine * sigma_bin + 1;
-    t.assign(5 * (size_t)K + 2, 0.0);
+    t.assign(6 * (size_t)K + 3, 0.0);
     const double sigma = res * sigma_bin / 2.355;
     const double sigma_square = sigma * sigma;
     const double normalization = 1 / sigma / std::sqrt(2 * M_PI) * res / refine;
@@ -156,7 +160,7 @@ void host_taps(int refine, int sigma_bin, float res, std::vector<double>& t) {
 
 // single unit tap (v1 gradient: delta 0, weight 1)
 void host_taps_unit(std::vector<double>& t) {
-    t.assign(7, 0.0);
+    t.assign(9, 0.0);
     t[0] = 1.0;
     host_prefix(t, 1);
 }
@@ -627,7 +631,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         ga.sp.res = res; ga.sp.nbins = T;
         ga.vis = c->vis.as<uint32_t>(); ga.vis_words = vis_words;
         ga.tap_w = c->taps.as<double>(); ga.tap_delta = ga.tap_w + K; ga.tap_g = ga.tap_w + 2 * K;
-        ga.tap_p0 = ga.tap_w + 3 * K; ga.tap_p1 = ga.tap_w + 4 * K + 1;
+        ga.tap_p0 = ga.tap_w + 3 * K; ga.tap_p1 = ga.tap_w + 4 * K + 1; ga.tap_pw = ga.tap_w + 5 * K + 2;
         ga.K = K;
         const bool v1 = mode == NLOS_MODE_GRADIENT_V1;
         ga.two_rs = v1 ? 0 : 2 * a->refine_scale * a->sigma_bin;

@@ -124,6 +124,7 @@ struct GradientArgs {
     const double* tap_g;     // [K] (float)(delta/sigma^2*2) widened
     const double* tap_p0;    // [K+1] prefix sums of (double)(float)w
     const double* tap_p1;    // [K+1] prefix sums of g * (double)(float)w
+    const double* tap_pw;    // [K+1] prefix sums of w (double): scalar gradients
     int K;
     int two_rs;              // 2*refine*sigma_bin (index of the centre tap)
     double r_over_res;       // refine / resolution
