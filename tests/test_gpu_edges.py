@@ -56,6 +56,19 @@ def test_degenerate_and_duplicate_faces_contribute_like_the_oracle(bunny, orc):
     assert np.isfinite(grad).all() and rel_l2(grad, g_ref) <= 1e-4
 
 
+def test_temporal_kernel_longer_than_the_tap_limit_is_an_error(bunny):
+    """4 * refine * sigma_bin + 1 taps are staged in LDS by the smoothing and gradient kernels: beyond 2048 the
+    call is refused with a status (the reference would just allocate)."""
+    from nlos_surface_optimization_amd import _lib
+    v, f = bunny
+    o, n = grid_sources(2, 0.2)
+    d = np.zeros((4, T))
+    with pytest.raises(_lib.NlosError, match="2048 taps"):
+        _render(v, f, o, n, 20000, refine=64, sb=9, data=d, weight=np.ones_like(d))
+    tr, grad, _ = _render(v, f, o, n, 20000, refine=10, sb=12, data=d, weight=np.ones_like(d))   # 481 taps: fine
+    assert np.isfinite(tr).all() and np.isfinite(grad).all() and tr.sum() > 0
+
+
 def test_out_of_range_face_index_is_an_error_not_a_crash(bunny):
     from nlos_surface_optimization_amd import _lib
     v, f = bunny
