@@ -14,23 +14,24 @@ namespace {
 // ------------------------------------------------------------- forward (grid)
 // Per-source perspective grid.  Every ray of a workgroup starts at the same wall point o, so the
 // triangles that can block the ray towards slope (mx, my) = (dx/dz, dy/dz) are exactly those whose
-// perspective projection from o covers that slope point.  Per source the workgroup builds, in LDS:
-//   * an R x R grid over slope space in CSR form (counting pass, block scan, fill pass) holding,
-//     per cell, the triangles whose projection (conservatively rasterised) overlaps the cell AND
-//     that are not entirely deeper than the deepest live face seen through that cell -- nothing
-//     deeper can be in front of any ray that will ever look the cell up;
-//   * a table of projected bounding boxes, quantised outwards to 1/256 of the grid extent.
-// A ray then walks only its own cell's list, rejects a candidate from the LDS bounding box (two
-// byte compares, no global access) and runs the exact triangle test on the few that remain.  The
-// kernel is bound by the vector-memory pipeline (divergent 48-byte record gathers), so everything
-// in front of the record load lives in LDS.  The accepted samples are identical to the BVH
-// path's: lists and boxes are supersets of what the exact test could report.  Sources for which
-// the scene is not strictly in front of the wall point, or whose grid overflows its LDS budget,
-// fall back to the stackless BVH traversal.
+// perspective projection from o covers that slope point.  Per source the workgroup builds, in LDS, an
+// R x R grid over slope space in CSR form (counting pass, block scan, fill pass) holding, per cell, one
+// 32-bit entry for every triangle whose projection (conservatively rasterised) overlaps the cell AND that
+// is not entirely deeper than the deepest live face seen through that cell -- nothing deeper can be in
+// front of any ray that will ever look the cell up.  The entry carries the triangle's quantised depth and
+// the sub-cell masks of its projected bounding box (layout below).
+// A ray walks only its own cell's list, rejects a candidate with three integer compares on the LDS word and
+// queues the survivors for the exact triangle test, which runs on dense lanes (wave-cooperative rounds).
+// The kernel is bound by VALU issue, so everything in front of the exact test is
+// integer work on LDS.  The accepted samples are identical to the BVH path's: lists and masks are
+// supersets of what the exact test could report.  Sources for which the scene is not strictly in front of
+// the wall point fall back to the stackless BVH traversal; sources whose cell lists overflow the entry
+// capacity restart on a coarser grid (grid_body<COARSE>), then with the whole CU's LDS, and only then
+// fall back to the BVH.
 struct GridView {
     float gx0, gy0, inv_cw, inv_ch;   // cell = floor((m - g0) * inv_c)
     float z0, inv_qz;                 // quantised depth = floor((z - z0) * inv_qz), zmax levels over the scene
-    int ib, zmax;                     // entry = index (ib bits) | x0:3 x1:3 y0:3 y1:3 | depth (32-12-ib bits)
+    int ib, zmax;                     // entry = depth (32 - 2 kSub - ib bits) | y mask | x mask | index (ib bits)
     int R;
 };
 
