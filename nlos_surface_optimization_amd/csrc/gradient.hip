@@ -279,7 +279,8 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
 #endif
 constexpr int kFmChunk = NLOS_FM_CHUNK, kFmBatch = NLOS_FM_BATCH, kFmThreads = NLOS_FM_THREADS;
 
-template <int FEAT, bool NC = false>
+// JIT: the taps of a measured jitter kernel (mode 4 of k_gradient: tap i -> bin b0 + i - offset)
+template <int FEAT, bool NC = false, bool JIT = false>
 __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(GradientArgs a, int src_per_group) {
     extern __shared__ double s_fm[];      // [acc 9*CHUNK][rows BATCH*T][delta K][p0 K+1][p1 K+1][list BATCH*CHUNK u16][ctl]
     const int T = a.sp.nbins, K = a.K, F = a.sc.F;
@@ -306,8 +307,13 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
     const int Ltot = a.src.total_sources > 0 ? a.src.total_sources : a.src.L;
     const double lbd = (double)a.sp.lb, resd = (double)a.sp.res, inv_res = 1.0 / resd;
     for (int i = tid; i < 9 * kFmChunk; i += kFmThreads) s_acc[i] = 0.0;
-    for (int i = tid; i < K; i += kFmThreads) s_delta[i] = a.tap_delta[i];
-    for (int i = tid; i <= K; i += kFmThreads) { s_p0[i] = a.tap_p0[i]; s_p1[i] = a.tap_p1[i]; }
+    if (JIT) {
+        // jitter taps: s_delta <- (float) jitter_weight, s_p0 <- jitter_grad
+        for (int i = tid; i < K; i += kFmThreads) { s_delta[i] = (double)(float)a.tap_w[i]; s_p0[i] = a.tap_g[i]; }
+    } else {
+        for (int i = tid; i < K; i += kFmThreads) s_delta[i] = a.tap_delta[i];
+        for (int i = tid; i <= K; i += kFmThreads) { s_p0[i] = a.tap_p0[i]; s_p1[i] = a.tap_p1[i]; }
+    }
     TapTables tt;
     tt.delta = s_delta; tt.p0 = s_p0; tt.p1 = s_p1; tt.K = K; tt.two_rs = a.two_rs; tt.r_over_res = a.r_over_res; tt.refine = a.refine;
 
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
                     V3 di;
                     float bw[3];
                     double twoh;
+                    int jit_b0 = 0;
                     if (NC) {
                         // row N: two legs, d(d1 + d2)/dp = dirA + dirB; P1 carries the confocal factor 2
                         GeoNC gc;
@@ -376,13 +383,27 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
                                               a.sc.vertex_normal, a.sc.albedo, g, t_self))
                             continue;
                         grad_vectors<FEAT>(f, g, on, a.normal_term, a.v1_style, a.sp.ggx_alpha, gv);
-                        di = g.dir * gv.inten_f;
+                        di = JIT ? g.dir : g.dir * gv.inten_f;
                         bw[0] = g.u; bw[1] = g.v; bw[2] = g.w;
                         twoh = (double)(2.0f * g.h);
+                        jit_b0 = (int)floorf((2.0f * g.h - a.sp.lb) / a.sp.res) - a.two_rs;
                     }
                     const V3 ce[3] = {cross(gv.t2, e0), cross(gv.t2, e1), cross(gv.t2, e2)};
                     double s0, s1;
-                    grouped_taps(tt, s_diff, T, twoh, lbd, resd, inv_res, s0, s1);
+                    if (JIT) {
+                        // jitter/transient_and_gradient.cpp:944-969, as in k_gradient<FEAT, 4>
+                        const double m2i = (double)gv.inten_f * (-2);
+                        s0 = 0.0;
+                        s1 = 0.0;
+                        const int i0 = max(0, -jit_b0), i1 = min(K, T - jit_b0);
+                        for (int i = i0; i < i1; ++i) {
+                            const float dd = (float)s_diff[jit_b0 + i];      // (float)(-2 d), see the row load
+                            s0 += (double)((float)s_delta[i] * dd);
+                            s1 += (double)(((float)(s_p0[i] * m2i) / a.sp.res) * dd);
+                        }
+                    } else {
+                        grouped_taps(tt, s_diff, T, twoh, lbd, resd, inv_res, s0, s1);
+                    }
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         const V3 A1 = gv.t1 * bw[q] + ce[q];
@@ -417,9 +438,10 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
 
 template <int FEAT>
 bool gradient_fm_launch(const GradientArgs& a, hipStream_t stream) {
-    // only the plain vertex gradient of meshes whose 3V accumulator cannot live in LDS
-    if (a.mode != 0 || a.sp.nbins * kFmBatch > 8192) return false;
-    if (a.src.sensor && (FEAT & FEAT_GGX)) return false;
+    // only the vertex gradient (Gaussian or jitter taps) of meshes whose 3V accumulator cannot live in LDS
+    if ((a.mode != 0 && a.mode != 4) || a.sp.nbins * kFmBatch > 8192) return false;
+    if (a.src.sensor && ((FEAT & FEAT_GGX) || a.mode == 4)) return false;
+    if (a.mode == 4 && (FEAT & (FEAT_GGX | FEAT_ALB))) return false;
     const size_t lds = ((size_t)9 * kFmChunk + (size_t)kFmBatch * a.sp.nbins + 3 * (size_t)a.K + 2) * sizeof(double) +
                        (size_t)kFmBatch * kFmChunk * 2 + 16;
     if (lds > 80 * 1024) return false;
@@ -435,6 +457,14 @@ bool gradient_fm_launch(const GradientArgs& a, hipStream_t stream) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient_fm<FEAT, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient_fm<FEAT, true>), dim3(nchunks, groups), dim3(kFmThreads), lds, stream, a, per);
+        }
+        return true;
+    }
+    if (a.mode == 4) {
+        if constexpr ((FEAT & (FEAT_GGX | FEAT_ALB)) == 0) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient_fm<FEAT, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient_fm<FEAT, false, true>), dim3(nchunks, groups), dim3(kFmThreads), lds, stream, a, per);
         }
         return true;
     }
@@ -499,7 +529,7 @@ void launch_gradient(const GradientArgs& a_in, hipStream_t stream) {
     // per-workgroup 3V-double accumulator while it fits beside the rest (one workgroup per CU at worst)
     const size_t acc = 3 * (size_t)a.sc.V * sizeof(double);
     a.lds_grad = ((a.mode == 0 || a.mode == 4) && a_in.lds_grad && lds + acc <= 150 * 1024) ? 1 : 0;
-    if (!a.lds_grad && a.mode == 0 && a_in.lds_grad) {
+    if (!a.lds_grad && (a.mode == 0 || a.mode == 4) && a_in.lds_grad) {
         // large meshes: face-major variant (per-face sums in LDS across sources, one scatter per face)
         bool done = false;
         switch (feat_of(a.sc, a.sp)) {
