@@ -237,7 +237,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     const int ntiles = TILED ? a.tiles_x * a.tiles_y : 1;
     const int tile = TILED ? (int)(blockIdx.x % (unsigned)ntiles) : 0;
     const int tile_x = TILED ? tile % a.tiles_x : 0, tile_y = TILED ? tile / a.tiles_x : 0;
-    const int mask_blocks = TILED ? max((a.tile_cap + 63) >> 6, (F + 63) >> 6) : (F + 63) >> 6;   // LDS sizing only
+    const int mask_blocks = TILED ? (a.tile_cap + 63) >> 6 : (F + 63) >> 6;   // LDS sizing only (tiles that visit all faces keep no masks)
     uint32_t* s_cell = reinterpret_cast<uint32_t*>(s_row + (rows_in_lds ? nbins : 0));
     uint32_t* s_union = s_cell + ((ncell + 2) & ~1);
     uint32_t* s_zc = s_union;                                                   // build phase
@@ -402,11 +402,11 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             }
         }
         const unsigned long long m = __ballot(live);
-        if (lane == 0) s_mask[b] = m;
+        if (lane == 0 && compact) s_mask[b] = m;      // (a tile that visits all F faces re-derives `dark` in the trace)
     }
     __syncthreads();
     FWD_STAMP();   // 0: setup + live-face masks + depth bounds
-    if (tid == 0) {
+    if (tid == 0 && compact) {
         uint32_t run = 0;
         for (int b = 0; b < nblocks; ++b) run += (uint32_t)__popcll(s_mask[b]);
         s_ctl[3] = (int)run;
@@ -913,7 +913,7 @@ bool forward_tiled_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t str
 #endif
     const int R = NLOS_TILE_R;
     const size_t R2 = (R + 1) / 2;
-    const size_t mask_blocks = std::max(((size_t)a.tile_cap + 63) / 64, ((size_t)a.sc.F + 63) / 64);
+    const size_t mask_blocks = ((size_t)a.tile_cap + 63) / 64;
     size_t union_words = ((R2 * R2 + 1) & ~(size_t)1) + 2 * mask_blocks;
     if (union_words < 8 * kQueueWords) union_words = 8 * kQueueWords;
     const size_t fixed = 32 + (rows_in_lds ? (size_t)a.sp.nbins * sizeof(double) : 0) + (((size_t)R * R + 2) & ~(size_t)1) * 4 +
