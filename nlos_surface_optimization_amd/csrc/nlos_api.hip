@@ -475,7 +475,8 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         // (front + back side, several depth layers) hold up to ~4.5x the mean, and the subset capacity is bounded by
         // the 14-bit entry index (overflowing tiles fall back to the BVH query by themselves);
         // scratch = 6 B per (source, tile, slot)
-        const int nt = (nF + 2999) / 3000;
+        static const int tile_tris = [] { const char* e = std::getenv("NLOS_TILE_TRIS"); return e && std::atoi(e) > 0 ? std::atoi(e) : 3000; }();
+        const int nt = (nF + tile_tris - 1) / tile_tris;
         int side = 1;
         while (side * side < nt) ++side;
         const long long tiles = (long long)side * side;
