@@ -236,13 +236,16 @@ typedef struct nlos_render_args {
     float   ggx_alpha;
     int32_t vertex_num;         /* VERTEX_GRADIENT */
     int32_t w_width;            /* GRADIENT_V1 */
-    int32_t reuse_bvh;          /* 1: vertices/faces unchanged since the previous call on this ctx */
+    int32_t reuse_bvh;          /* 1: skip the scene build and use the tree of generation `mesh_generation`
+                                   (fails unless that is still the tree the ctx holds) */
     /* autograd support (additions; the reference always derives the residual itself) */
     const double *residual;     /* [L,T] or NULL. GRADIENT: use this as `difference` instead of
                                    (data - transient) * weight; data/weight may then be NULL */
     int32_t keep_visibility;    /* TRANSIENT: also record the per-sample visibility cache */
-    int32_t reuse_visibility;   /* GRADIENT with residual: skip pass 1, reuse the cache recorded by the
-                                   previous render on this ctx (same mesh, sources, samples, seed) */
+    int32_t reuse_visibility;   /* GRADIENT with residual: skip pass 1 and reuse the visibility cache of
+                                   generation `visibility_generation` (fails unless the ctx still holds that
+                                   cache, recorded on the tree it currently holds, for the same sources,
+                                   samples and seed) */
     int32_t force_bvh;          /* 1: occlusion by BVH traversal only (default 0: per-source perspective
                                    grid in LDS, tiled over several workgroups per source for meshes beyond
                                    6.2 k faces; identical results).  2 (diagnostic): tiled grid with a tiny
@@ -265,6 +268,9 @@ typedef struct nlos_render_args {
     const double *jitter_weight; /* [jitter_length] or NULL */
     const double *jitter_grad;   /* [jitter_length] (GRADIENT mode) */
     int32_t jitter_offset, jitter_length;
+    /* stale-cache protection for reuse_bvh / reuse_visibility: the values nlos_ctx_mesh_generation() /
+     * nlos_ctx_visibility_generation() returned after the render whose tree / cache is to be reused */
+    int64_t mesh_generation, visibility_generation;
 } nlos_render_args;
 
 int  nlos_sizeof_render_args(void);                 /* for FFI layout checks */
@@ -273,6 +279,52 @@ void nlos_render_args_init(nlos_render_args *a);   /* zero + defaults (clamp=1, 
 /* Enqueue one render on `stream` (hipStream_t as void*; NULL = default stream).
  * Asynchronous: returns after the launches are queued. */
 int nlos_render(nlos_ctx *ctx, const nlos_render_args *args, void *stream);
+
+/* Every scene build gives the ctx a new mesh generation, every pass 1 that records the visibility cache a
+ * new visibility generation (0 = the ctx holds none).  A caller that wants a later render to reuse either
+ * (reuse_bvh / reuse_visibility) reads the generation after the render that produced it and hands it back;
+ * any build or pass 1 in between makes the reuse fail instead of silently contracting against another
+ * mesh's tree or visibility. */
+int64_t nlos_ctx_mesh_generation(const nlos_ctx *ctx);
+int64_t nlos_ctx_visibility_generation(const nlos_ctx *ctx);
+
+/* Which kernels the last nlos_render on this ctx took, and why (nothing falls back silently). */
+enum {
+    NLOS_PATH_NONE       = 0,
+    NLOS_PATH_GRID       = 1,   /* per-source perspective grid, one workgroup per source */
+    NLOS_PATH_TILED_GRID = 2,   /* one workgroup per (source, slope-space tile) */
+    NLOS_PATH_BVH        = 3    /* stackless BVH traversal per ray packet (5-6x slower on the bunny) */
+};
+enum {
+    NLOS_REASON_NONE          = 0,
+    NLOS_REASON_FORCED        = 1,  /* force_bvh = 1 */
+    NLOS_REASON_TINY_MESH     = 2,  /* F < 64 */
+    NLOS_REASON_LDS           = 3,  /* rows + cell tables leave no room for the cell lists */
+    NLOS_REASON_TILE_LIMITS   = 4,  /* more than 1024 tiles, or the tile tables do not fit LDS */
+    NLOS_REASON_GGX_PAIRS     = 5,  /* non-confocal pairs with a feature the grid passes do not carry */
+    NLOS_REASON_LARGE_MESH    = 6   /* F beyond the single-workgroup grid: tiled */
+};
+typedef struct nlos_path_info {
+    int32_t backend;            /* NLOS_PATH_* of pass 1 (NONE if pass 1 was skipped) */
+    int32_t reason;             /* NLOS_REASON_* : why not NLOS_PATH_GRID */
+    int32_t grid_R;             /* cells per side of the (tile's) grid */
+    int32_t tiles, tile_cap;    /* tiled grid: tiles per source, triangle capacity of a tile subset */
+    int32_t chunks;             /* source chunks pass 1 was split into (tile scratch bounded to 32 GB) */
+    int32_t rows_in_lds;        /* 1: histogram rows accumulated in LDS, 0: global atomics */
+    int32_t gradient_kernel;    /* 0 none, 1 source-major with LDS accumulator, 2 source-major with global
+                                   atomics, 3 face-major */
+    /* per-workgroup outcomes of the grid launches (sources, or (source, tile) pairs); -1 unless counted */
+    int64_t workgroups, coarsened, big_lds, bvh_queries;
+} nlos_path_info;
+/* count_workgroups != 0 synchronises the device and fills the four counters from the launch's flags:
+ * `coarsened` restarted on a coarser grid inside the kernel, `big_lds` were redone by the second launch
+ * with the whole CU's LDS, `bvh_queries` traced their rays through the in-kernel BVH query (scene not
+ * strictly in front of the wall point, or cell lists that fit nowhere). */
+int nlos_ctx_last_path(nlos_ctx *ctx, nlos_path_info *out, int count_workgroups);
+/* Deferred device-side status of earlier renders on this ctx (face index out of range seen by the scene
+ * build): nlos_render checks it without synchronising whenever the flag has already arrived; this call
+ * synchronises the device and checks it now.  NLOS_OK or NLOS_ERR_ARG. */
+int nlos_ctx_check(nlos_ctx *ctx);
 
 /* closest-hit batch (row E) on device pointers: out3 [N,3] and/or out1 [N] */
 int nlos_intersect(nlos_ctx *ctx, const float *origins, const float *dirs, int n_rays,

@@ -70,7 +70,33 @@ class RenderArgs(ctypes.Structure):
         ("jitter_grad", ctypes.c_void_p),
         ("jitter_offset", ctypes.c_int32),
         ("jitter_length", ctypes.c_int32),
+        ("mesh_generation", ctypes.c_int64),
+        ("visibility_generation", ctypes.c_int64),
     ]
+
+
+class PathInfo(ctypes.Structure):
+    """Mirror of `nlos_path_info` (include/nlos_hip.h): the kernels the last render took and why."""
+    _fields_ = [
+        ("backend", ctypes.c_int32),
+        ("reason", ctypes.c_int32),
+        ("grid_R", ctypes.c_int32),
+        ("tiles", ctypes.c_int32),
+        ("tile_cap", ctypes.c_int32),
+        ("chunks", ctypes.c_int32),
+        ("rows_in_lds", ctypes.c_int32),
+        ("gradient_kernel", ctypes.c_int32),
+        ("workgroups", ctypes.c_int64),
+        ("coarsened", ctypes.c_int64),
+        ("big_lds", ctypes.c_int64),
+        ("bvh_queries", ctypes.c_int64),
+    ]
+
+
+PATH_NAMES = {0: "none", 1: "grid", 2: "tiled-grid", 3: "bvh"}
+REASON_NAMES = {0: "", 1: "force_bvh", 2: "mesh below 64 faces", 3: "rows and cell tables leave no LDS for the cell lists",
+                4: "tile limits", 5: "non-confocal pairs with GGX", 6: "mesh beyond one workgroup's grid"}
+GRADIENT_KERNEL_NAMES = {0: "none", 1: "source-major, LDS accumulator", 2: "source-major, global atomics", 3: "face-major"}
 
 
 MODE_TRANSIENT = 0
@@ -129,6 +155,10 @@ SYMBOLS = {
     "nlos_ctx_last_timing": (_I, [_P, _P]),
     "nlos_ctx_timing_reset": (None, [_P]),
     "nlos_ctx_timing_mean": (_I, [_P, _P, _P]),
+    "nlos_ctx_mesh_generation": (_I64, [_P]),
+    "nlos_ctx_visibility_generation": (_I64, [_P]),
+    "nlos_ctx_last_path": (_I, [_P, ctypes.POINTER(PathInfo), _I]),
+    "nlos_ctx_check": (_I, [_P]),
 }
 
 

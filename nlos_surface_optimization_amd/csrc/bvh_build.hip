@@ -561,8 +561,8 @@ void launch_build_bvh(const BuildArgs& a, hipStream_t stream) {
     if (refit > lds && refit <= lds_max) lds = refit;
     const int split = (refit > lds_max && a.F > 1) ? 1 : 0;      // beyond the LDS refit: chip-wide launches
     if (!split) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_bvh), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+        note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_bvh), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds), "hipFuncSetAttribute(dynamic LDS)");
         hipLaunchKernelGGL(k_build_bvh, dim3(1), dim3(BT), lds, stream, a, (int)(lds / sizeof(uint32_t)), 0);
         return;
     }

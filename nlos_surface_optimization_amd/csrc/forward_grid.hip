@@ -532,6 +532,8 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     // lockstep loop: a wave is as slow as its longest list.  Handing out the live faces in
     // buckets of similar list length (longest first) makes the 64 lists of a wave comparable.
     const bool use_grid = s_ctl[1] == 0;
+    // diagnostics (nlos_ctx_last_path): this workgroup traces its rays through the in-kernel BVH query
+    if (!use_grid && a.retry && tid == 0) a.retry[blockIdx.x] = 0x200;
 #ifdef NLOS_FWD_STAMPS
     if (TILED && tid == 0 && a.dbg && !use_grid && !ident) atomicAdd((unsigned long long*)&a.dbg[20], 1ull);   // entry overflow
     if (TILED && tid == 0 && a.dbg) atomicMax((unsigned long long*)&a.dbg[21], (unsigned long long)s_ctl[2]);
@@ -870,7 +872,11 @@ constexpr size_t kGridLdsBudget = 78 * 1024 - 128;
 
 template <int FEAT, int NCM = 0>
 bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
-    if (a.force_bvh || a.tile_list || a.sc.F > 8191 || a.sc.F < 64) return false;     // 13-bit triangle index in the cell entries
+    LaunchNote scratch_note;
+    LaunchNote& note = tl_note ? *tl_note : scratch_note;
+    if (a.force_bvh) { note.reason = 1; return false; }
+    if (a.sc.F < 64) { note.reason = 2; return false; }
+    if (a.tile_list || a.sc.F > 8191) { note.reason = 6; return false; }              // 13-bit triangle index in the cell entries
 #ifndef NLOS_GRID_RSCALE
 #define NLOS_GRID_RSCALE 0.5f
 #endif
@@ -882,16 +888,18 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
     if (union_words < 8 * kQueueWords) union_words = 8 * kQueueWords;
     const size_t fixed = 32 + (rows_in_lds ? (size_t)a.sp.nbins * sizeof(double) : 0) + (((size_t)R * R + 2) & ~(size_t)1) * 4 +
                          ((union_words + 1) & ~(size_t)1) * 4;
-    if (fixed + 4 * 2 * (size_t)a.sc.F > kGridLdsBudget || !a.live) return false;      // want room for >= 2 entries per face
+    if (fixed + 4 * 2 * (size_t)a.sc.F > kGridLdsBudget || !a.live) { note.reason = 3; return false; }   // want room for >= 2 entries per face
     size_t cap = (kGridLdsBudget - fixed) / 4;
     const size_t lds = fixed + cap * 4;
     const size_t lds_big = 150 * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM, false, 0>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM, false, 0>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(k_forward_grid, LDS)");
     if (a.retry)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM, false, 1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
-    if (a.retry) (void)hipMemsetAsync(a.retry, 0, sizeof(int) * (size_t)a.src.L, stream);
+        note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM, false, 1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big), "hipFuncSetAttribute(k_forward_grid big-LDS)");
+    if (a.retry) note_hip(hipMemsetAsync(a.retry, 0, sizeof(int) * (size_t)a.src.L, stream), "hipMemsetAsync(retry)");
+    note.backend = 1; note.reason = 0; note.grid_R = R; note.tiles = 1; note.tile_cap = 0;
+    note.retry_workgroups = a.retry ? a.src.L : 0;
     // kScan slots of slack: the walk reads kScan entries per trip and may touch the slots after the last list
     const int last_pass = a.retry ? 1 : 0;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, false, 0>), dim3(a.src.L), dim3(512), lds, stream, a, rows_in_lds, R,
@@ -905,7 +913,11 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
 // meshes beyond one workgroup's LDS: one workgroup per (source, slope-space tile)
 template <int FEAT, int NCM = 0>
 bool forward_tiled_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
-    if (a.force_bvh || !a.tile_list || !a.tile_count || !a.live || a.tiles_x * a.tiles_y > 1024 || a.tiles_x < 1 || a.tiles_y < 1) return false;
+    LaunchNote scratch_note;
+    LaunchNote& note = tl_note ? *tl_note : scratch_note;
+    if (a.force_bvh) { note.reason = 1; return false; }
+    if (!a.tile_list || !a.tile_count || !a.live) return false;                      // (reason recorded by the single-workgroup launcher)
+    if (a.tiles_x * a.tiles_y > 1024 || a.tiles_x < 1 || a.tiles_y < 1) { note.reason = 4; return false; }
     if ((NCM != 0) != (a.src.sensor != nullptr)) return false;
     uint32_t* const visout = NCM == 1 ? a.vis2 : a.vis;
 #ifndef NLOS_TILE_R
@@ -918,20 +930,22 @@ bool forward_tiled_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t str
     if (union_words < 8 * kQueueWords) union_words = 8 * kQueueWords;
     const size_t fixed = 32 + (rows_in_lds ? (size_t)a.sp.nbins * sizeof(double) : 0) + (((size_t)R * R + 2) & ~(size_t)1) * 4 +
                          ((union_words + 1) & ~(size_t)1) * 4;
-    if (fixed + 4 * 4096 > kGridLdsBudget) return false;
+    if (fixed + 4 * 4096 > kGridLdsBudget) { note.reason = 4; return false; }
     const size_t cap = (kGridLdsBudget - fixed) / 4;
     const size_t lds = fixed + cap * 4;
     // partial rows / visibility words of the tiles are combined with atomics: start from zero
     if (NCM != 1 && rows_in_lds && a.rows) launch_zero_f64(a.rows, (size_t)a.src.L * a.sp.nbins, stream);
-    if (visout) (void)hipMemsetAsync(visout, 0, sizeof(uint32_t) * (size_t)a.src.L * a.vis_words * a.sc.F, stream);
+    if (visout) note_hip(hipMemsetAsync(visout, 0, sizeof(uint32_t) * (size_t)a.src.L * a.vis_words * a.sc.F, stream), "hipMemsetAsync(vis)");
     const size_t nwg = (size_t)a.src.L * a.tiles_x * a.tiles_y;
-    (void)hipMemsetAsync(a.tile_count, 0, sizeof(int) * 2 * nwg, stream);      // subset sizes + retry flags
+    note_hip(hipMemsetAsync(a.tile_count, 0, sizeof(int) * 2 * nwg, stream), "hipMemsetAsync(tile_count)");      // subset sizes + retry flags
+    note.backend = 2; note.reason = 6; note.grid_R = R; note.tiles = a.tiles_x * a.tiles_y; note.tile_cap = a.tile_cap;
+    note.retry_workgroups = (int)nwg;
     hipLaunchKernelGGL(k_tile_bin, dim3(a.src.L), dim3(512), 0, stream, a, R, NCM == 1 ? 1 : 0);
     // second launch for the tiles whose cell lists overflow: the whole CU's LDS for one workgroup
     const size_t lds_big = 150 * 1024;
     const size_t cap_big = (lds_big - fixed) / 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
+    note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big), "hipFuncSetAttribute(k_forward_grid tiled)");
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, true>), dim3((unsigned)nwg), dim3(512), lds, stream, a, rows_in_lds, R,
                        (int)cap - kScan, 0, 1);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, true>), dim3((unsigned)nwg), dim3(512), lds_big, stream, a, rows_in_lds,
@@ -953,6 +967,7 @@ bool grid_dispatch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
                 return forward_grid_launch<FEAT, 1>(p1, 0, stream) && forward_grid_launch<FEAT, 2>(a, rows_in_lds, stream);
             }
         }
+        if (tl_note) tl_note->reason = a.force_bvh ? 1 : 5;
         return false;
     }
     if (forward_grid_launch<FEAT>(a, rows_in_lds, stream)) return true;

@@ -454,22 +454,22 @@ bool gradient_fm_launch(const GradientArgs& a, hipStream_t stream) {
     groups = (a.src.L + per - 1) / per;
     if (a.src.sensor) {
         if constexpr ((FEAT & FEAT_GGX) == 0) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient_fm<FEAT, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient_fm<FEAT, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(dynamic LDS)");
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient_fm<FEAT, true>), dim3(nchunks, groups), dim3(kFmThreads), lds, stream, a, per);
         }
         return true;
     }
     if (a.mode == 4) {
         if constexpr ((FEAT & (FEAT_GGX | FEAT_ALB)) == 0) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient_fm<FEAT, false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient_fm<FEAT, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(dynamic LDS)");
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient_fm<FEAT, false, true>), dim3(nchunks, groups), dim3(kFmThreads), lds, stream, a, per);
         }
         return true;
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient_fm<FEAT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
+    note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient_fm<FEAT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds), "hipFuncSetAttribute(dynamic LDS)");
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient_fm<FEAT>), dim3(nchunks, groups), dim3(kFmThreads), lds, stream, a, per);
     return true;
 }
@@ -478,14 +478,14 @@ template <int FEAT, int MODE>
 void gradient_launch2(const GradientArgs& a, int grid, size_t lds, hipStream_t stream, bool wide = false) {
     if constexpr (MODE == 0) {
         if (wide) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, 0, false, 1024>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, 0, false, 1024>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(dynamic LDS)");
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, 0, false, 1024>), dim3(grid), dim3(1024), lds, stream, a);
             return;
         }
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, MODE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(dynamic LDS)");
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, MODE>), dim3(grid), dim3(NLOS_GRAD_NT), lds, stream, a);
 }
 
@@ -494,13 +494,13 @@ void gradient_launch(const GradientArgs& a, int grid, size_t lds, hipStream_t st
     if (a.src.sensor) {
         if constexpr ((FEAT & FEAT_GGX) == 0) {
             if (wide) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, 0, true, 1024>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, 0, true, 1024>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(dynamic LDS)");
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, 0, true, 1024>), dim3(grid), dim3(1024), lds, stream, a);
                 return;
             }
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, 0, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, 0, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(dynamic LDS)");
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, 0, true>), dim3(grid), dim3(NLOS_GRAD_NT), lds, stream, a);
         }
         return;
@@ -542,8 +542,9 @@ void launch_gradient(const GradientArgs& a_in, hipStream_t stream) {
             case 6: done = gradient_fm_launch<6>(a, stream); break;
             default: done = gradient_fm_launch<7>(a, stream); break;
         }
-        if (done) return;
+        if (done) { if (tl_note) tl_note->gradient_kernel = 3; return; }
     }
+    if (tl_note) tl_note->gradient_kernel = a.lds_grad ? 1 : 2;
     if (a.lds_grad) lds += acc;
     // persistent workgroups: as many as can be co-resident (512 threads each, <= 128 VGPRs -> 4 per CU)
     int per_cu = (int)(160 * 1024 / (lds + 64));

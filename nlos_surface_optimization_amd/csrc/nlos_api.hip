@@ -78,6 +78,17 @@ struct nlos_ctx {
     DevBuf keys0, keys1, idx0, idx1, child, range, parent, arrive, box, status;
     DevBuf nodes, tris, facerec, face_id, tri_zmin;
     int built_F = -1, built_V = -1;
+    // stale-cache protection: every scene build / recorded pass 1 takes the next value of one counter
+    int64_t gen_counter = 0, mesh_gen = 0, vis_gen = 0;
+    // what the last render did (nlos_ctx_last_path)
+    nlos_path_info path;
+    int path_retry_workgroups = 0;
+    // deferred device-side status (bad face index seen by the scene build): copied to pinned host memory behind
+    // the build, looked at -- without synchronising -- by the next nlos_render, or by nlos_ctx_check
+    int* h_status = nullptr;
+    hipEvent_t status_ev = nullptr;
+    bool status_pending = false;
+    bool status_clear = true;        // status[0] is sticky across builds; cleared once its error has been reported
     // render scratch
     DevBuf vis, diff, fine, taps, rows_tmp, grad_tmp, live;
     DevBuf reg_normal, reg_area, reg_owner;
@@ -87,7 +98,7 @@ struct nlos_ctx {
     DevBuf io[16];
     // what the visibility cache currently describes
     struct VisKey { int L = -1, F = -1, V = -1, spt = -1; long long off = -1; uint64_t seed = 0; float lb = 0, ub = 0;
-                    int feat = -1; } vis_key;
+                    int feat = -1; int64_t mesh_gen = -1; } vis_key;
     // timing
     // ring of event sets: no host sync inside a timed loop, read back after the final sync
     static constexpr int kRing = 256;
@@ -180,8 +191,33 @@ int ensure_taps(nlos_ctx* c, int kind, int refine, int sigma_bin, float res, hip
     return NLOS_OK;
 }
 
-int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bool reuse, hipStream_t st) {
-    if (reuse && c->built_F == nF && c->built_V == nV) return NLOS_OK;
+// Deferred status of the scene builds (face index out of range).  `wait` synchronises with the copy.
+int check_status(nlos_ctx* c, bool wait) {
+    if (!c->status_pending || !c->status_ev || !c->h_status) return NLOS_OK;
+    if (wait) {
+        HIP_TRY(hipEventSynchronize(c->status_ev));
+    } else {
+        hipError_t q = hipEventQuery(c->status_ev);
+        if (q != hipSuccess) { (void)hipGetLastError(); return NLOS_OK; }     // not there yet: look again next time
+    }
+    c->status_pending = false;
+    if (c->h_status[0] & 1) {
+        c->h_status[0] = 0;
+        c->status_clear = true;
+        return fail(NLOS_ERR_ARG, "face index out of range [0, numVertices) in an earlier render on this context "
+                                  "(the out-of-range indices were read as vertex 0)");
+    }
+    return NLOS_OK;
+}
+
+int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bool reuse, int64_t reuse_gen, hipStream_t st) {
+    if (reuse) {
+        // the caller vouches that vertices/faces are those of generation reuse_gen; any build since then
+        // (another mesh, another vertex position) makes that claim stale
+        if (c->built_F == nF && c->built_V == nV && reuse_gen != 0 && reuse_gen == c->mesh_gen) return NLOS_OK;
+        return fail(NLOS_ERR_ARG, "nlos_render: reuse_bvh requested but the context no longer holds the tree of that "
+                                  "mesh generation (pass the value nlos_ctx_mesh_generation() returned after the render to reuse)");
+    }
     const size_t n_nodes = 2 * (size_t)nF - 1;
     int rc = 0;
     rc |= c->keys0.ensure(sizeof(uint32_t) * nF);
@@ -200,7 +236,9 @@ int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bo
     rc |= c->face_id.ensure(sizeof(int) * (size_t)nF);
     rc |= c->tri_zmin.ensure(sizeof(float) * (size_t)nF);
     if (rc) return NLOS_ERR_HIP;
-    HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int) * 64, st));
+    // status[0] (bad face index) is sticky until the host has reported it; the rest is per-build scratch
+    if (c->status_clear) { HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int), st)); c->status_clear = false; }
+    HIP_TRY(hipMemsetAsync(c->status.as<int>() + 1, 0, sizeof(int) * 63, st));
     nlos::BuildArgs b;
     b.vertices = V; b.faces = F; b.V = nV; b.F = nF;
     b.keys0 = c->keys0.as<uint32_t>(); b.keys1 = c->keys1.as<uint32_t>();
@@ -221,6 +259,20 @@ int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bo
     }
 #endif
     c->built_F = nF; c->built_V = nV;
+    c->mesh_gen = ++c->gen_counter;
+    // the build kernel's status word follows the build to pinned host memory; nobody waits for it here
+    if (!c->h_status) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_status), 64, hipHostMallocDefault));
+        c->h_status[0] = 0;
+        HIP_TRY(hipEventCreateWithFlags(&c->status_ev, hipEventDisableTiming));
+    }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { cs = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
+    if (cs == hipStreamCaptureStatusNone) {     // (a captured render replays without the host looking on)
+        HIP_TRY(hipMemcpyAsync(c->h_status, c->status.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(c->status_ev, st));
+        c->status_pending = true;
+    }
     return NLOS_OK;
 }
 
@@ -290,6 +342,8 @@ void nlos_ctx_destroy(nlos_ctx* c) {
     for (DevBuf* b : all) b->release();
     for (DevBuf& b : c->io) b.release();
     for (hipEvent_t& e : c->ring) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
+    if (c->status_ev) { hipError_t r = hipEventDestroy(c->status_ev); (void)r; }
+    if (c->h_status) { hipError_t r = hipHostFree(c->h_status); (void)r; }
     delete c;
 }
 
@@ -420,8 +474,16 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     const int spt = 1 + ((a->num_samples - 1) / nF);
     const int vis_words = (spt + 31) / 32;
 
+    int rc = check_status(c, false);
+    if (rc) return rc;
+    nlos::LaunchNote note;
+    struct NoteScope { NoteScope(nlos::LaunchNote* n) { nlos::tl_note = n; } ~NoteScope() { nlos::tl_note = nullptr; } } note_scope(&note);
+    std::memset(&c->path, 0, sizeof(c->path));
+    c->path.workgroups = c->path.coarsened = c->path.big_lds = c->path.bvh_queries = -1;
+    c->path_retry_workgroups = 0;
+
     mark(c, 0, st);
-    int rc = ensure_bvh(c, a->vertices, nV, a->faces, nF, a->reuse_bvh != 0, st);
+    rc = ensure_bvh(c, a->vertices, nV, a->faces, nF, a->reuse_bvh != 0, a->mesh_generation, st);
     if (rc) return rc;
     mark(c, 1, st);
 
@@ -464,6 +526,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.retry = nullptr;
     fa.tiles_x = fa.tiles_y = fa.tile_cap = 0;
     static const int tile_threshold = [] { const char* e = std::getenv("NLOS_TILE_THRESHOLD"); return e ? std::atoi(e) : 6200; }();
+    int chunk_L = L > 0 ? L : 1;                       // sources per pass-1 launch
     if (nF <= tile_threshold && a->force_bvh != 1) {
         rc = c->live.ensure(sizeof(uint16_t) * (size_t)(L > 0 ? L : 1) * nF + 16);
         if (!rc) rc = c->tile_count.ensure(sizeof(int) * (size_t)(L > 0 ? L : 1) + 16);
@@ -483,19 +546,29 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         long long tcap = 6LL * nF / tiles + 512;
         if (tcap > 16383) tcap = 16383;
         if (a->force_bvh == 2) tcap = 64;              // diagnostic: force the subset-overflow fallback of the tiles
-        const unsigned long long slots = (unsigned long long)L * tiles * tcap;
-        if (slots * 6ull <= (32ull << 30)) {
-            rc = c->live.ensure(sizeof(uint16_t) * slots + 16);
-            if (!rc) rc = c->tile_list.ensure(sizeof(uint32_t) * slots + 16);
-            if (!rc) rc = c->tile_count.ensure(sizeof(int) * 2 * (size_t)L * tiles + 16);
-            if (rc) return rc;
-            fa.tile_count = c->tile_count.as<int>();
-            fa.retry = fa.tile_count + (size_t)L * tiles;
-            fa.live = c->live.as<uint16_t>();
-            fa.tile_list = c->tile_list.as<uint32_t>();
-            fa.tiles_x = fa.tiles_y = side;
-            fa.tile_cap = (int)tcap;
-        }
+        // the per-(source, tile) subsets are the largest scratch of the path (6 B per slot): bounded to 32 GB by
+        // rendering the sources in chunks (NLOS_TILE_SCRATCH_MAX overrides the bound; nlos_ctx_last_path reports
+        // the number of chunks)
+        static const unsigned long long scratch_max = [] {
+            const char* e = std::getenv("NLOS_TILE_SCRATCH_MAX");
+            const unsigned long long v = e ? std::strtoull(e, nullptr, 10) : 0ull;
+            return v > 0 ? v : (32ull << 30);
+        }();
+        const unsigned long long per_source = (unsigned long long)tiles * (unsigned long long)tcap;
+        unsigned long long max_l = scratch_max / (6ull * per_source);
+        if (max_l < 1) max_l = 1;
+        if ((unsigned long long)L > max_l) chunk_L = (int)max_l;
+        const unsigned long long slots = (unsigned long long)chunk_L * per_source;
+        rc = c->live.ensure(sizeof(uint16_t) * slots + 16);
+        if (!rc) rc = c->tile_list.ensure(sizeof(uint32_t) * slots + 16);
+        if (!rc) rc = c->tile_count.ensure(sizeof(int) * 2 * (size_t)chunk_L * tiles + 16);
+        if (rc) return rc;
+        fa.tile_count = c->tile_count.as<int>();
+        fa.retry = fa.tile_count + (size_t)chunk_L * tiles;
+        fa.live = c->live.as<uint16_t>();
+        fa.tile_list = c->tile_list.as<uint32_t>();
+        fa.tiles_x = fa.tiles_y = side;
+        fa.tile_cap = (int)tcap;
     }
 #ifdef NLOS_FWD_STAMPS
     HIP_TRY(hipMemsetAsync(c->status.p, 0, 64 * sizeof(int), st));
@@ -513,9 +586,15 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     key.L = L; key.F = nF; key.V = nV; key.spt = spt; key.off = a->source_offset; key.seed = a->seed;
     key.lb = lb; key.ub = ub;
     key.feat = (vn ? 1 : 0) | (alb ? 2 : 0) | (sp.use_ggx ? 4 : 0) | (sp.clamp ? 8 : 0) | (a->sensor ? 16 : 0);
+    key.mesh_gen = c->mesh_gen;
     const bool skip_pass1 = a->reuse_visibility != 0;
     if (skip_pass1) {
+        // the cache must be the one the caller saw being recorded (generation), recorded on the tree the ctx
+        // holds now (pass 2 reads the sorted face records of that tree), for the same sources and samples
         const nlos_ctx::VisKey& k = c->vis_key;
+        if (a->visibility_generation == 0 || a->visibility_generation != c->vis_gen || k.mesh_gen != c->mesh_gen)
+            return fail(NLOS_ERR_ARG, "nlos_render: reuse_visibility requested but the context no longer holds the visibility "
+                                      "cache of that generation (another render or scene build ran on it since)");
         if (!(k.L == key.L && k.F == key.F && k.V == key.V && k.spt == key.spt && k.off == key.off && k.seed == key.seed &&
               k.lb == key.lb && k.ub == key.ub && k.feat == key.feat))
             return fail(NLOS_ERR_ARG, "nlos_render: reuse_visibility requested but the cache does not match this render");
@@ -525,8 +604,10 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         if (rc) return rc;
         fa.vis = c->vis.as<uint32_t>();
         c->vis_key = key;
+        if (!skip_pass1) c->vis_gen = ++c->gen_counter;
     } else {
         c->vis_key = nlos_ctx::VisKey();
+        c->vis_gen = 0;
     }
     double* transient = a->transient;
     if (mode == NLOS_MODE_GRADIENT && a->residual && !transient) {
@@ -548,7 +629,23 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
             fa.rows = transient;
         }
     }
-    if (!skip_pass1) nlos::launch_forward(fa, st);
+    int n_chunks = 0;
+    for (int l0 = 0; !skip_pass1 && l0 < L; l0 += chunk_L, ++n_chunks) {
+        nlos::ForwardArgs fc = fa;
+        fc.src.L = L - l0 < chunk_L ? L - l0 : chunk_L;
+        fc.src.origin += 3 * (size_t)l0; fc.src.normal += 3 * (size_t)l0;
+        if (fc.src.sensor) { fc.src.sensor += 3 * (size_t)l0; fc.src.sensor_normal += 3 * (size_t)l0; }
+        fc.src.source_offset += l0;
+        if (fc.rows) fc.rows += (size_t)l0 * rb;
+        if (fc.vis) fc.vis += (size_t)l0 * vis_words * nF;
+        if (fc.vis2) fc.vis2 += (size_t)l0 * vis_words * nF;
+        if (fc.tile_count) fc.retry = fc.tile_count + (size_t)fc.src.L * fc.tiles_x * fc.tiles_y;   // flags follow this chunk's subset sizes
+        nlos::launch_forward(fc, st);
+    }
+    c->path.backend = note.backend; c->path.reason = note.reason; c->path.grid_R = note.grid_R;
+    c->path.tiles = note.tiles; c->path.tile_cap = note.tile_cap; c->path.chunks = n_chunks;
+    c->path.rows_in_lds = note.rows_in_lds;
+    c->path_retry_workgroups = note.retry_workgroups;
 #ifdef NLOS_FWD_STAMPS
     {
         long long h[24];
@@ -677,7 +774,41 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     }
     mark(c, 4, st);
     c->ev_valid = c->timing;
+    c->path.gradient_kernel = note.gradient_kernel;
+    if (note.err != hipSuccess)
+        return fail(NLOS_ERR_HIP, std::string(note.err_what ? note.err_what : "launch") + ": " + hipGetErrorString(note.err));
     HIP_TRY(hipGetLastError());
+    return NLOS_OK;
+}
+
+int64_t nlos_ctx_mesh_generation(const nlos_ctx* c) { return c ? c->mesh_gen : 0; }
+int64_t nlos_ctx_visibility_generation(const nlos_ctx* c) { return c ? c->vis_gen : 0; }
+
+int nlos_ctx_check(nlos_ctx* c) {
+    if (!c) return fail(NLOS_ERR_ARG, "nlos_ctx_check: NULL ctx");
+    DeviceGuard guard(c->device);
+    HIP_TRY(hipDeviceSynchronize());
+    return check_status(c, true);
+}
+
+int nlos_ctx_last_path(nlos_ctx* c, nlos_path_info* out, int count_workgroups) {
+    if (!c || !out) return fail(NLOS_ERR_ARG, "nlos_ctx_last_path: NULL argument");
+    *out = c->path;
+    if (!count_workgroups || c->path_retry_workgroups <= 0) return NLOS_OK;
+    DeviceGuard guard(c->device);
+    // the flags of the (last chunk's) grid launches: single-workgroup grid -> tile_count[0 .. L), tiled grid ->
+    // behind the subset sizes
+    const int n = c->path_retry_workgroups;
+    const int* flags = c->tile_count.as<int>() + (c->path.backend == NLOS_PATH_TILED_GRID ? (size_t)n : 0);
+    std::vector<int> h((size_t)n);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h.data(), flags, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    out->workgroups = n; out->coarsened = 0; out->big_lds = 0; out->bvh_queries = 0;
+    for (int v : h) {
+        if (v == 1) ++out->big_lds;
+        else if (v == 0x200) ++out->bvh_queries;
+        else if (v >= 0x100 && v < 0x200) ++out->coarsened;
+    }
     return NLOS_OK;
 }
 
@@ -688,7 +819,7 @@ int nlos_intersect(nlos_ctx* c, const float* origins, const float* dirs, int n_r
     if (n_rays < 0 || (n_rays > 0 && (!origins || !dirs))) return fail(NLOS_ERR_ARG, "nlos_intersect: bad rays");
     DeviceGuard guard(c->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    int rc = ensure_bvh(c, vertices, V, faces, F, false, st);
+    int rc = ensure_bvh(c, vertices, V, faces, F, false, 0, st);
     if (rc) return rc;
     nlos::IntersectArgs ia;
     ia.sc = scene_view(c, F, V, nullptr, nullptr);
@@ -829,7 +960,11 @@ struct HostCall {
         }
         int st[4] = {0, 0, 0, 0};
         e = hipMemcpy(st, c->status.p, sizeof(st), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && (st[0] & 1)) return fail(NLOS_ERR_ARG, "face index out of range [0, numVertices)");
+        c->status_pending = false;
+        if (e == hipSuccess && (st[0] & 1)) {
+            c->status_clear = true;
+            return fail(NLOS_ERR_ARG, "face index out of range [0, numVertices)");
+        }
         return NLOS_OK;
     }
 };

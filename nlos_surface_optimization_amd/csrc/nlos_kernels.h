@@ -5,6 +5,20 @@
 
 namespace nlos {
 
+// What the launchers decided for the current render (host side only).  nlos_render points `tl_note` at
+// its note before it calls the launchers; they record the back-end they chose, why, and the first HIP
+// error of an attribute call or launch -- nothing falls back or fails silently (nlos_ctx_last_path).
+struct LaunchNote {
+    int backend = 0, reason = 0, grid_R = 0, tiles = 0, tile_cap = 0, rows_in_lds = 0, gradient_kernel = 0;
+    int retry_workgroups = 0;        // entries of the retry / path-code array the grid launches wrote
+    hipError_t err = hipSuccess;
+    const char* err_what = nullptr;
+};
+extern thread_local LaunchNote* tl_note;
+inline void note_hip(hipError_t e, const char* what) {
+    if (e != hipSuccess && tl_note && tl_note->err == hipSuccess) { tl_note->err = e; tl_note->err_what = what; }
+}
+
 // ------------------------------------------------------------------ BVH build
 struct BuildArgs {
     const float* vertices;   // [V,3]

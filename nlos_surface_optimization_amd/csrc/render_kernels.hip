@@ -137,6 +137,8 @@ __global__ __launch_bounds__(256) void k_zero_f64(double* p, size_t n) {
 
 }  // namespace
 
+thread_local LaunchNote* tl_note = nullptr;
+
 void launch_forward(const ForwardArgs& a, hipStream_t stream) {
     if (a.src.L <= 0) return;
     const size_t row_bytes = (size_t)a.sp.nbins * sizeof(double);
@@ -146,7 +148,9 @@ void launch_forward(const ForwardArgs& a, hipStream_t stream) {
     static const size_t row_lds_max = [] { const char* e = std::getenv("NLOS_ROW_LDS_MAX"); return e ? (size_t)std::atol(e) : (size_t)9 * 1024; }();
     const int rows_in_lds = (!a.mode_intensity && row_bytes <= row_lds_max) ? 1 : 0;
     if (!rows_in_lds && !a.mode_intensity) launch_zero_f64(a.rows, (size_t)a.src.L * a.sp.nbins, stream);
+    if (tl_note) tl_note->rows_in_lds = rows_in_lds;
     if (launch_forward_grid(a, rows_in_lds, stream)) return;
+    if (tl_note) tl_note->backend = 3;       // NLOS_PATH_BVH; the reason was recorded by the grid dispatcher
     launch_forward_bvh(a, rows_in_lds, stream);
 }
 
@@ -156,7 +160,8 @@ void launch_smooth(const SmoothArgs& a, hipStream_t stream) {
     const size_t row = (size_t)a.T * a.refine * sizeof(double);
     const int row_in_lds = wbytes + row <= 64 * 1024 ? 1 : 0;       // two or more workgroups per CU; W alone is <= 16 KB (API limit of 2048 taps)
     const size_t lds = wbytes + (row_in_lds ? row : 0);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+             "hipFuncSetAttribute(k_smooth)");
     hipLaunchKernelGGL(k_smooth, dim3(a.L), dim3(256), lds, stream, a, row_in_lds);
 }
 

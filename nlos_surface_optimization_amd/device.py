@@ -90,6 +90,33 @@ class TransientRenderer:
                                                   ctypes.cast(ctypes.byref(cnt), ctypes.c_void_p)), "nlos_ctx_timing_mean")
         return tuple(float(x) for x in buf), cnt.value
 
+    def mesh_generation(self):
+        """Generation of the scene tree the context holds (changes with every build)."""
+        return int(self._lib.nlos_ctx_mesh_generation(self._h))
+
+    def visibility_generation(self):
+        """Generation of the visibility cache the context holds (0: none; changes with every recorded pass 1)."""
+        return int(self._lib.nlos_ctx_visibility_generation(self._h))
+
+    def last_path(self, count=False):
+        """Which kernels the last render took and why, as a dict (`count=True` synchronises and adds the
+        per-workgroup outcomes of the grid launches: coarsened / big-LDS / in-kernel BVH query)."""
+        info = _lib.PathInfo()
+        _lib.check(self._lib.nlos_ctx_last_path(self._h, ctypes.byref(info), 1 if count else 0), "nlos_ctx_last_path")
+        d = {"backend": _lib.PATH_NAMES.get(info.backend, str(info.backend)),
+             "reason": _lib.REASON_NAMES.get(info.reason, str(info.reason)),
+             "grid_R": info.grid_R, "tiles": info.tiles, "tile_cap": info.tile_cap, "chunks": info.chunks,
+             "rows_in_lds": bool(info.rows_in_lds),
+             "gradient_kernel": _lib.GRADIENT_KERNEL_NAMES.get(info.gradient_kernel, str(info.gradient_kernel))}
+        if count and info.workgroups >= 0:
+            d.update(workgroups=int(info.workgroups), coarsened=int(info.coarsened), big_lds=int(info.big_lds),
+                     bvh_queries=int(info.bvh_queries))
+        return d
+
+    def check(self):
+        """Synchronise and raise if an earlier render on this context met a face index out of range."""
+        _lib.check(self._lib.nlos_ctx_check(self._h), "nlos_ctx_check")
+
     def _args(self, mode, origin, normal, vertices, faces, num_sample, lower_bound, upper_bound,
               resolution, refine_scale=1, sigma_bin=1, vertex_normal=None, albedo=None,
               source_offset=0, total_sources=0, alpha=None, seed=None, force_bvh=False,
@@ -157,8 +184,12 @@ class TransientRenderer:
     def render_gradient(self, origin, normal, vertices, faces, num_sample, lower_bound, upper_bound,
                         resolution, data=None, weight=None, refine_scale=10, sigma_bin=1, testing_flag=1,
                         loss_flag=0, vertex_normal=None, albedo=None, alpha=None, gradient=None,
-                        normal_term=-1, residual=None, reuse_visibility=False, reuse_bvh=False, **kw):
-        """Rows D,G,GD. Returns (transient, gradient [V,3] f64 (accumulated into if given), pathlengths)."""
+                        normal_term=-1, residual=None, reuse_visibility=False, reuse_bvh=False,
+                        mesh_generation=0, visibility_generation=0, **kw):
+        """Rows D,G,GD. Returns (transient, gradient [V,3] f64 (accumulated into if given), pathlengths).
+        `reuse_bvh` / `reuse_visibility` need the generations read after the render whose tree / cache they
+        reuse (mesh_generation(), visibility_generation()); with reuse_visibility pass 1 is skipped and the
+        returned transient is None."""
         a = self._args(_lib.MODE_GRADIENT, origin, normal, vertices, faces, num_sample, lower_bound,
                        upper_bound, resolution, refine_scale, sigma_bin, vertex_normal, albedo,
                        alpha=alpha, **kw)
@@ -168,7 +199,7 @@ class TransientRenderer:
         for t, n in ((data, "data"), (weight, "weight"), (residual, "residual")):
             if t is not None:
                 assert tuple(t.shape) == (L, T), "%s should be LxB" % n
-        transient = torch.empty((L, T), dtype=torch.float64, device=self.device)
+        transient = None if reuse_visibility else torch.empty((L, T), dtype=torch.float64, device=self.device)
         path = torch.empty(T, dtype=torch.float64, device=self.device)
         if gradient is None:
             gradient = torch.zeros((vertices.shape[0], 3), dtype=torch.float64, device=self.device)
@@ -180,6 +211,7 @@ class TransientRenderer:
         a.testing_flag, a.loss_test, a.normal_term = int(testing_flag), int(loss_flag), int(normal_term)
         a.reuse_visibility = 1 if reuse_visibility else 0
         a.reuse_bvh = 1 if reuse_bvh else 0
+        a.mesh_generation, a.visibility_generation = int(mesh_generation), int(visibility_generation)
         self._run(a, (origin, normal, vertices, faces, vertex_normal, albedo, data, weight, residual))
         return transient, gradient, path
 
@@ -306,9 +338,15 @@ class TransientFunction(torch.autograd.Function):
     def forward(ctx, vertices, renderer, origin, normal, faces, num_sample, lower_bound, upper_bound,
                 resolution, refine_scale, sigma_bin, normal_term, seed):
         v = vertices.detach().contiguous()
+        # the function being differentiated: the reference's gradient driver renders the forward unsmoothed
+        # for sigma_bin < 5 and Gaussian-smoothed at refine_scale otherwise
+        # (smoothed_transient/stratifiedStreamedGradientRenderer.cpp:521-524)
+        fwd_refine = refine_scale if sigma_bin >= 5 else 1
         transient, _ = renderer.render_transient(origin, normal, v, faces, num_sample, lower_bound,
-                                                 upper_bound, resolution, 1, 1, keep_visibility=True,
+                                                 upper_bound, resolution, fwd_refine, sigma_bin, keep_visibility=True,
                                                  total_sources=1, seed=seed)
+        # backward may reuse this render's tree and visibility cache only while the context still holds them
+        ctx.generations = (renderer.mesh_generation(), renderer.visibility_generation())
         ctx.renderer = renderer
         ctx.save_for_backward(v, origin, normal, faces)
         ctx.params = (num_sample, lower_bound, upper_bound, resolution, refine_scale, sigma_bin, normal_term, seed)
@@ -320,12 +358,14 @@ class TransientFunction(torch.autograd.Function):
         num_sample, lb, ub, res, refine, sigma_bin, normal_term, seed = ctx.params
         residual = (-0.5 * grad_out).to(torch.float64).contiguous()
         r = ctx.renderer
-        try:
+        mesh_gen, vis_gen = ctx.generations
+        if (r.mesh_generation(), r.visibility_generation()) == (mesh_gen, vis_gen):
             _, grad, _ = r.render_gradient(origin, normal, v, faces, num_sample, lb, ub, res, residual=residual,
                                            refine_scale=refine, sigma_bin=sigma_bin, normal_term=normal_term,
-                                           reuse_visibility=True, reuse_bvh=True, total_sources=1, seed=seed)
-        except _lib.NlosError:
-            # another render used this context since forward(): redo pass 1
+                                           reuse_visibility=True, reuse_bvh=True, mesh_generation=mesh_gen,
+                                           visibility_generation=vis_gen, total_sources=1, seed=seed)
+        else:
+            # another render or scene build used this context since forward(): build and trace again
             _, grad, _ = r.render_gradient(origin, normal, v, faces, num_sample, lb, ub, res, residual=residual,
                                            refine_scale=refine, sigma_bin=sigma_bin, normal_term=normal_term,
                                            total_sources=1, seed=seed)

@@ -57,10 +57,16 @@ class ShardedRenderer:
 
     def render_gradient(self, origin, normal, *args, **kw):
         """origin/normal/data/weight are the LOCAL blocks. Returns (local transient rows,
-        globally reduced gradient, pathlengths)."""
+        globally reduced gradient, pathlengths).  A caller-supplied `gradient=` buffer is accumulated into as
+        the renderer does (v2 semantics) -- AFTER the reduction, so that what it already holds (e.g. a
+        regulariser gradient present on every rank) is not multiplied by the world size."""
+        into = kw.pop("gradient", None)
         transient, gradient, path = self.renderer.render_gradient(
             origin, normal, *args, source_offset=self.lo, total_sources=self.n_sources, **kw)
         all_reduce_gradient(gradient, self.group)
+        if into is not None:
+            into += gradient
+            gradient = into
         return transient, gradient, path
 
     def gather_transient(self, local_rows):

@@ -11,7 +11,6 @@ the per-face terms over a vertex's incident faces; the reference stores them wit
 wins) -- `set_regulariser_overwrite(True)` selects that behaviour (highest incident face wins).
 """
 import ctypes
-import math
 
 import numpy as np
 
@@ -54,9 +53,13 @@ def renderStreamedCurvatureGradient(vertices, faces, gradient):
 
 
 def _num_bins(lower_bound, upper_bound, resolution):
-    # renderer.pyx:101 -- python float math on the already-float32-rounded scalars
-    lb, ub, res = np.float32(lower_bound), np.float32(upper_bound), np.float32(resolution)
-    return math.ceil((float(ub) - float(lb)) / float(res))
+    """Row length the native side writes: ceil((ub - lb) / res) in float32
+    (smoothed_transient/stratifiedStreamedGradientRenderer.cpp:514-515).  renderer.pyx:101 validates the
+    caller's arrays against the same expression in Python doubles; where the two disagree (a quotient within
+    float32 rounding of an integer) the reference strides its rows by one count and checks them against the
+    other.  Shapes are validated against the count the kernels use, so such a call fails the shape assertion
+    instead of writing mis-strided rows."""
+    return _lib.num_bins(lower_bound, upper_bound, resolution)
 
 
 def _common(origin, normal, vertices, faces):

@@ -1,0 +1,204 @@
+"""Context state of the device path: generations that guard reuse_bvh / reuse_visibility against stale
+caches, the report of which kernels a render took (nothing falls back silently), chunked pass 1 when the
+tile scratch is bounded, and the deferred bad-face-index status of the device-pointer path."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, grid_sources, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+LB, UB, RES, T = 0.625, 1.625, 2.0 ** -9, 512
+
+
+def _dev_setup(bunny, n=3, seed=2):
+    import torch
+    from nlos_surface_optimization_amd import device as nd
+    v, f = bunny
+    o, nrm = grid_sources(n, 0.2)
+    dev = torch.device("cuda", 0)
+    r = nd.TransientRenderer(dev, seed=seed)
+    tv, tf, to, tn = (torch.from_numpy(x).to(dev) for x in (v, f, o, nrm))
+    return r, tv, tf, to, tn, o, nrm
+
+
+def test_backward_after_another_forward_differentiates_its_own_mesh(bunny, orc):
+    """forward(v_a), forward(v_b) on the same renderer (same F, V, sources, seed), then backward of a: the gradient
+    must be a's (smoothed_transient/transient_and_gradient.cpp:843-1007 evaluated at v_a), not a contraction against
+    b's tree and visibility."""
+    import torch
+    from nlos_surface_optimization_amd import device as nd
+    r, tv, tf, to, tn, o, nrm = _dev_setup(bunny)
+    v, f = bunny
+    ns = 9000
+    L = o.shape[0]
+    rs = np.random.RandomState(3)
+    vb_np = (v + 0.004 * rs.standard_normal(v.shape)).astype(np.float32)
+    va = tv.clone().requires_grad_(True)
+    vb = torch.from_numpy(vb_np).to(tv.device).requires_grad_(True)
+    data = torch.zeros((L, T), dtype=torch.float64, device=tv.device)
+    Ta = nd.render_transient_autograd(r, va, to, tn, tf, ns, LB, UB, RES)
+    gens_a = (r.mesh_generation(), r.visibility_generation())
+    Tb = nd.render_transient_autograd(r, vb, to, tn, tf, ns, LB, UB, RES)
+    assert (r.mesh_generation(), r.visibility_generation()) != gens_a
+    ((data - Ta) ** 2).sum().div(L).backward()
+    ((data - Tb) ** 2).sum().div(L).backward()
+    w = np.ones((L, T))
+    _, ga, _ = orc.render_gradient(o, nrm, v, f, ns, LB, UB, RES, np.zeros((L, T)), w, accel=1, seed=2)
+    _, gb, _ = orc.render_gradient(o, nrm, vb_np, f, ns, LB, UB, RES, np.zeros((L, T)), w, accel=1, seed=2)
+    assert rel_l2(ga, gb) > 1e-2                                  # the two meshes have clearly different gradients
+    assert rel_l2(va.grad.double().cpu().numpy(), ga) <= 1e-4
+    assert rel_l2(vb.grad.double().cpu().numpy(), gb) <= 1e-4
+    # the sum of two graphs through one renderer
+    vc = tv.clone().requires_grad_(True)
+    vd = torch.from_numpy(vb_np).to(tv.device).requires_grad_(True)
+    tot = nd.render_transient_autograd(r, vc, to, tn, tf, ns, LB, UB, RES) + \
+        nd.render_transient_autograd(r, vd, to, tn, tf, ns, LB, UB, RES)
+    ((data - tot) ** 2).sum().backward()
+    assert torch.isfinite(vc.grad).all() and torch.isfinite(vd.grad).all()
+    r.close()
+
+
+def test_reuse_flags_need_the_matching_generation(bunny):
+    import torch
+    from nlos_surface_optimization_amd import _lib
+    r, tv, tf, to, tn, o, nrm = _dev_setup(bunny)
+    ns = 9000
+    L = o.shape[0]
+    assert r.mesh_generation() == 0 and r.visibility_generation() == 0
+    tr, _ = r.render_transient(to, tn, tv, tf, ns, LB, UB, RES, keep_visibility=True)
+    mg, vg = r.mesh_generation(), r.visibility_generation()
+    assert mg > 0 and vg > 0
+    res = (0.1 * tr).contiguous()
+    _, g_full, _ = r.render_gradient(to, tn, tv, tf, ns, LB, UB, RES, residual=res)
+    mg2, vg2 = r.mesh_generation(), r.visibility_generation()
+    assert mg2 > mg and vg2 > vg
+    # reuse with the current generations: same gradient, no transient
+    t_none, g_reuse, _ = r.render_gradient(to, tn, tv, tf, ns, LB, UB, RES, residual=res, reuse_visibility=True,
+                                           reuse_bvh=True, mesh_generation=mg2, visibility_generation=vg2)
+    assert t_none is None and rel_l2(g_reuse.cpu().numpy(), g_full.cpu().numpy()) <= 1e-12
+    assert (r.mesh_generation(), r.visibility_generation()) == (mg2, vg2)      # a reuse records nothing new
+    for kw in (dict(mesh_generation=mg, visibility_generation=vg2),             # stale tree
+               dict(mesh_generation=mg2, visibility_generation=vg),             # stale cache
+               dict()):                                                         # no generation at all
+        with pytest.raises(_lib.NlosError):
+            r.render_gradient(to, tn, tv, tf, ns, LB, UB, RES, residual=res, reuse_visibility=True, reuse_bvh=True, **kw)
+    # a forward-only render that keeps no cache invalidates the visibility generation
+    r.render_transient(to, tn, tv, tf, ns, LB, UB, RES)
+    assert r.visibility_generation() == 0
+    r.close()
+
+
+def test_last_path_reports_backend_reason_and_workgroup_outcomes(bunny, mannequin):
+    import torch
+    from nlos_surface_optimization_amd import mesh_io
+    r, tv, tf, to, tn, o, nrm = _dev_setup(bunny)
+    ns = 9000
+    r.render_transient(to, tn, tv, tf, ns, LB, UB, RES)
+    p = r.last_path(count=True)
+    assert p["backend"] == "grid" and p["reason"] == "" and p["tiles"] == 1 and p["chunks"] == 1 and p["rows_in_lds"]
+    assert p["gradient_kernel"] == "none"
+    assert p["workgroups"] == 9 and p["big_lds"] == 0 and p["bvh_queries"] == 0
+    r.render_transient(to, tn, tv, tf, ns, LB, UB, RES, force_bvh=True)
+    p = r.last_path()
+    assert p["backend"] == "bvh" and p["reason"] == "force_bvh"
+    # a wall point inside the scene's depth range: that workgroup traces through the in-kernel BVH query
+    o2 = o.copy()
+    o2[4, 2] = 0.45
+    to2 = torch.from_numpy(o2).to(tv.device)
+    data = torch.zeros((9, T), dtype=torch.float64, device=tv.device)
+    r.render_gradient(to2, tn, tv, tf, ns, LB, UB, RES, data=data, weight=torch.ones_like(data))
+    p = r.last_path(count=True)
+    assert p["backend"] == "grid" and p["bvh_queries"] == 1 and p["gradient_kernel"] == "source-major, LDS accumulator"
+    # 2048 bins: rows stay in global memory
+    r.render_transient(to, tn, tv, tf, ns, 0.625, 1.625, 2.0 ** -11)
+    assert not r.last_path()["rows_in_lds"]
+    # tiny mesh -> BVH back-end, with the reason
+    vq = np.array([[-.25, -.25, .38], [.25, -.25, .38], [.25, .25, .38], [-.25, .25, .38]], np.float32)
+    fq = np.array([[0, 2, 1], [0, 3, 2]], np.int32)
+    r.render_transient(to, tn, torch.from_numpy(vq).to(tv.device), torch.from_numpy(fq).to(tv.device), 256, 0.0, 2.0, 2.0 ** -5)
+    p = r.last_path()
+    assert p["backend"] == "bvh" and p["reason"] == "mesh below 64 faces"
+    # large mesh -> tiled grid, face-major gradient
+    v, f = bunny
+    v2, f2 = mesh_io.subdivide(v, f, 1)
+    tv2, tf2 = torch.from_numpy(v2).to(tv.device), torch.from_numpy(f2).to(tv.device)
+    r.render_gradient(to, tn, tv2, tf2, 4 * f2.shape[0], LB, UB, RES, data=data, weight=torch.ones_like(data))
+    p = r.last_path(count=True)
+    assert p["backend"] == "tiled-grid" and p["tiles"] >= 4 and p["chunks"] == 1 and p["gradient_kernel"] == "face-major"
+    assert p["workgroups"] == 9 * p["tiles"]
+    r.close()
+
+
+_CHUNK_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from nlos_surface_optimization_amd import device as nd, mesh_io
+d = np.load(%r)
+v, f = mesh_io.subdivide(np.ascontiguousarray(d["v"], np.float32), np.ascontiguousarray(d["f"], np.int32), 1)
+g = np.linspace(-0.22, 0.22, 3)
+o = np.array([[x, y, 0] for y in g for x in g], np.float32)[:7]
+n = np.tile(np.array([0, 0, 1], np.float32), (7, 1))
+dev = torch.device("cuda", 0)
+r = nd.TransientRenderer(dev, seed=4)
+tv, tf, to, tn = (torch.from_numpy(x).to(dev) for x in (v, f, o, n))
+ns = 4 * f.shape[0]
+t, _ = r.render_transient(to, tn, tv, tf, ns, 0.625, 1.625, 2.0 ** -9, keep_visibility=True)
+p = r.last_path(count=True)
+data = (1.3 * t).contiguous()
+_, g1, _ = r.render_gradient(to, tn, tv, tf, ns, 0.625, 1.625, 2.0 ** -9, data=data, weight=torch.ones_like(data))
+np.savez(sys.argv[1], t=t.cpu().numpy(), g=g1.cpu().numpy(), chunks=p["chunks"], backend=p["backend"])
+"""
+
+
+def test_bounded_tile_scratch_renders_the_sources_in_chunks(tmp_path):
+    """The tiled grid's per-(source, tile) subsets are bounded (32 GB; here NLOS_TILE_SCRATCH_MAX forces 3 sources
+    per chunk): pass 1 then runs in chunks of sources -- same rows, same gradient, still the tiled grid (round 1
+    dropped to the BVH back-end, silently)."""
+    golden = os.path.join(ROOT, "tests", "golden", "bunny_5k.npz")
+    outs = []
+    for tag, limit in (("one", None), ("chunked", None)):
+        env = dict(os.environ)
+        out = str(tmp_path / (tag + ".npz"))
+        if tag == "chunked":
+            # 9 tiles x (6 F / 9 + 512) slots x 6 B per source ~ 0.74 MB at F = 19 868: room for 3 sources
+            env["NLOS_TILE_SCRATCH_MAX"] = str(3 * 800 * 1024)
+        subprocess.run([sys.executable, "-c", _CHUNK_SCRIPT % (ROOT, golden), out], check=True, env=env, timeout=600)
+        outs.append(np.load(out))
+    a, b = outs
+    assert str(a["backend"]) == "tiled-grid" and str(b["backend"]) == "tiled-grid"
+    assert int(a["chunks"]) == 1 and int(b["chunks"]) >= 2
+    assert a["t"].sum() > 0 and rel_l2(b["t"], a["t"]) <= 1e-12
+    assert rel_l2(b["g"], a["g"]) <= 1e-10
+
+
+def test_device_path_surfaces_a_bad_face_index(bunny):
+    """nlos_render on device pointers cannot validate indices on the host; the scene build flags them (and reads
+    vertex 0 instead, so nothing faults).  The flag follows the build to pinned memory and is raised by
+    nlos_ctx_check, or by the next render once it has arrived."""
+    import torch
+    from nlos_surface_optimization_amd import _lib
+    r, tv, tf, to, tn, o, nrm = _dev_setup(bunny)
+    ns = 9000
+    bad = tf.clone()
+    bad[5, 1] = tv.shape[0] + 3
+    r.render_transient(to, tn, tv, bad, ns, LB, UB, RES)       # asynchronous: enqueued without an error
+    with pytest.raises(_lib.NlosError, match="face index out of range"):
+        r.check()
+    r.check()                                                   # reported once
+    t, _ = r.render_transient(to, tn, tv, tf, ns, LB, UB, RES)  # the context stays usable
+    r.check()
+    assert float(t.sum()) > 0
+    # without an explicit check the next render reports it (the flag has arrived after a synchronise)
+    r.render_transient(to, tn, tv, bad, ns, LB, UB, RES)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.NlosError, match="face index out of range"):
+        r.render_transient(to, tn, tv, tf, ns, LB, UB, RES)
+    t2, _ = r.render_transient(to, tn, tv, tf, ns, LB, UB, RES)
+    r.check()
+    assert rel_l2(t2.cpu().numpy(), t.cpu().numpy()) <= 1e-12
+    r.close()
