@@ -148,10 +148,10 @@ def workload_config(args, g, T, F, V, spt, L_total, world):
                     ("SUBDIVIDED mesh x4^%d (side measurement, not the metric) " % args.subdivide if args.subdivide else "") +
                     ("RE-DECIMATED mesh (side measurement, not the metric) " if args.faces else "") +
                     ("forward-only " if args.forward_only else "forward+gradient ") +
-                    "%d confocal sources (%s) x %d bins, %s (F=%d, V=%d), num_sample=%d "
+                    "%dx%d confocal sources%s x %d bins, %s (F=%d, V=%d), num_sample=%d "
                     "(spt=%d), refine=10, sigma_bin=1, BVH rebuilt every step" % (
-                        L_total, ("one %dx%d grid split over %d ranks" % (g, g, world)) if args.scaling == "strong" or world == 1
-                        else ("%dx%d per rank" % (g, g)), T, args.mesh, F, V, args.num_sample, spt),
+                        g, g, "" if world == 1 else (" split over %d ranks" % world if args.scaling == "strong" else " per rank"),
+                        T, args.mesh, F, V, args.num_sample, spt),
         "sources_total": L_total, "faces": F, "bins": T, "spt": spt,
         "parallelism": "source-block sharding x%d + one all-reduce of the 3V gradient" % world,
     }
