@@ -49,7 +49,7 @@ def test_config2_and_3_bunny_32x32_512_bins_vs_oracle(bunny, orc):
     data = _noisy_data(t_ref, 1)
     w = np.ones_like(data)
     t_ref2, g_ref, _ = orc.render_gradient(o, n, v, f, ns, lb, ub, res, data, w, accel=1, seed=0)
-    assert np.array_equal(t_ref2, t_ref)
+    assert rel_l2(t_ref2, t_ref) <= 1e-13        # (the oracle's threads sum their buffers in any order)
     r = nd.TransientRenderer(torch.device("cuda", 0), seed=0)
     to, tn, tv, tf, td, tw = _tensors(o, n, v, f, data, w)
     t_fwd, _ = r.render_transient(to, tn, tv, tf, ns, lb, ub, res)                    # cfg 2
