@@ -171,6 +171,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the ~13 s CPU leg (the parity gate still runs, on a small block)")
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="after the timed steps: a loop of at least this long, reported as sustained_ms_per_step (0 = skip)")
+    ap.add_argument("--diagnostic-no-gate", action="store_true",
+                    help="kernel-variant experiments (tools/ab_pmc.sh builds variants whose results are deliberately wrong): a "
+                         "failing parity gate does not stop the run, but NO JSON line is printed -- per-kernel ms go to stderr, exit code 3")
     ap.add_argument("--subdivide", type=int, default=0,
                     help="side measurement (not the metric): 1->4 midpoint subdivision passes of the mesh (F x 4^n)")
     ap.add_argument("--mesh", choices=["bunny_5k", "mannequin"], default="bunny_5k",
@@ -334,7 +337,8 @@ def run_rank(args, backend):
         flag = torch.tensor([1.0 if gate_ok else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         gate_ok = bool(flag.item() > 0.5)
-    if not gate_ok:
+    diagnostic = bool(args.diagnostic_no_gate and not gate_ok)
+    if not gate_ok and not diagnostic:
         if rank == 0:
             sys.stderr.write("bench.py: PARITY GATE FAILED, nothing timed: %s\n" % json.dumps(parity))
         if world > 1:
@@ -396,6 +400,13 @@ def run_rank(args, backend):
             t_s = float(ts.item())
         sustained_ms = 1e3 * t_s / sustained_steps
 
+    if diagnostic:
+        if rank == 0:
+            sys.stderr.write("bench.py: DIAGNOSTIC run (parity gate failed, no result line): ms/step %.3f kernel_ms %s\n" % (
+                1e3 * elapsed / args.steps, json.dumps(dict(zip(["bvh_build", "k_forward", "k_residual", "k_gradient"], [float(x) for x in kt])))))
+        if world > 1:
+            dist.destroy_process_group()
+        return 3
     if rank == 0:
         samples_per_step = L_total * F * spt          # all ranks
         ms = 1e3 * elapsed / args.steps

@@ -121,7 +121,10 @@ __device__ __forceinline__ void leaf_records(const BuildArgs& a, const int* __re
     a.tris[kTriStride * j] = make_float4(tr.p0.x, tr.p0.y, tr.p0.z, tr.e1.x);
     a.tris[kTriStride * j + 1] = make_float4(tr.e1.y, tr.e1.z, tr.e2.x, tr.e2.y);
     a.tris[kTriStride * j + 2] = make_float4(tr.e2.z, tr.ng.x, tr.ng.y, tr.ng.z);
-    a.tris[kTriStride * j + 3] = make_float4(fminf(fminf(p0.z, p1.z), p2.z), __int_as_float(f), 0.0f, 0.0f);
+    // per-face constants of the sample map, evaluated once per build with load_face()'s own expressions
+    // (render_common.h; ng == cross(p1 - p0, p2 - p0) bit for bit): area and 1 / (2 area)
+    const float area = sqrtf(dot(tr.ng, tr.ng)) / 2.0f;
+    a.tris[kTriStride * j + 3] = make_float4(fminf(fminf(p0.z, p1.z), p2.z), __int_as_float(f), area, 1.0f / (2.0f * area));
     a.facerec[4 * j] = make_float4(p0.x, p0.y, p0.z, p1.x);
     a.facerec[4 * j + 1] = make_float4(p1.y, p1.z, p2.x, p2.y);
     a.facerec[4 * j + 2] = make_float4(p2.z, __int_as_float(f), __int_as_float(i0), __int_as_float(i1));

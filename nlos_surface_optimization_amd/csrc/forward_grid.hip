@@ -8,6 +8,8 @@
 // transient_and_gradient.cpp:122-237); only the "is anything in front of this ray" query differs.
 #include "render_common.h"
 
+#include <type_traits>
+
 namespace nlos {
 namespace {
 
@@ -38,6 +40,25 @@ struct GridView {
 __device__ __forceinline__ int cell_coord(float m, float g0, float inv_c, int R) {
     int c = (int)floorf((m - g0) * inv_c);
     return min(max(c, 0), R - 1);
+}
+
+// Face + triangle of sorted slot j for the sample map.  Same values as load_face() / load_tri() (render_common.h,
+// nlos_device.h): e1, e2 are make_tri()'s own subtractions, ng == cross(p1 - p0, p2 - p0) bit for bit, and area,
+// 1 / (2 area) were evaluated by the scene build with load_face()'s expressions -- once per step instead of once
+// per (source, face).
+template <int FEAT>
+__device__ __forceinline__ void load_face_tri(const SceneView& sc, int j, Face& f, Tri& tr) {
+    const float4 fa = sc.facerec[4 * j], fb = sc.facerec[4 * j + 1], fc = sc.facerec[4 * j + 2];
+    const float4 tc = sc.tris[kTriStride * j + 2], td = sc.tris[kTriStride * j + 3];
+    f.p0 = mk(fa.x, fa.y, fa.z); f.p1 = mk(fa.w, fb.x, fb.y); f.p2 = mk(fb.z, fb.w, fc.x);
+    f.fid = __float_as_int(fc.y);
+    f.i0 = __float_as_int(fc.z); f.i1 = __float_as_int(fc.w);
+    f.i2 = (FEAT & (FEAT_VN | FEAT_ALB)) ? __float_as_int(sc.facerec[4 * j + 3].x) : 0;
+    tr.p0 = f.p0; tr.e1 = f.p0 - f.p1; tr.e2 = f.p2 - f.p0;
+    tr.ng = mk(tc.y, tc.z, tc.w);
+    f.area = td.z;
+    f.degenerate = !(f.area > 0.0f);
+    f.fn = tr.ng * td.w;
 }
 
 struct Proj2 { float ax, ay, bx, by, cx, cy; };
@@ -96,15 +117,18 @@ __device__ __forceinline__ uint32_t make_entry(const GridView& g, const BBoxF& b
     return (zq << (g.ib + 2 * kSub)) | (ym << (g.ib + kSub)) | (xm << g.ib) | (uint32_t)k;
 }
 
-// conservative rasterisation of a projected triangle: fn(xx, yy) for every overlapped cell
-template <class Fn>
-__device__ __forceinline__ void raster_tri(const GridView& g, const Proj2& q, Fn fn) {
+// conservative rasterisation of a projected triangle: fn(xx, yy) for every overlapped cell.  `pre(cx0, cx1, cy0, cy1)`
+// sees the cell range of the bounding box first and may drop the triangle before the edge functions are set up.
+struct RasterAll { __device__ __forceinline__ bool operator()(int, int, int, int) const { return true; } };
+template <class Fn, class Pre = RasterAll>
+__device__ __forceinline__ void raster_tri(const GridView& g, const Proj2& q, Fn fn, Pre pre = Pre()) {
     const float cw = __builtin_amdgcn_rcpf(g.inv_cw), ch = __builtin_amdgcn_rcpf(g.inv_ch);
     const float mgx = 1e-3f * cw, mgy = 1e-3f * ch;          // >> fp32 rounding of the projection
     const int cx0 = cell_coord(fminf(fminf(q.ax, q.bx), q.cx) - mgx, g.gx0, g.inv_cw, g.R);
     const int cx1 = cell_coord(fmaxf(fmaxf(q.ax, q.bx), q.cx) + mgx, g.gx0, g.inv_cw, g.R);
     const int cy0 = cell_coord(fminf(fminf(q.ay, q.by), q.cy) - mgy, g.gy0, g.inv_ch, g.R);
     const int cy1 = cell_coord(fmaxf(fmaxf(q.ay, q.by), q.cy) + mgy, g.gy0, g.inv_ch, g.R);
+    if (!pre(cx0, cx1, cy0, cy1)) return;
     // edge functions, oriented so that the inside is >= 0
     const float area = (q.bx - q.ax) * (q.cy - q.ay) - (q.by - q.ay) * (q.cx - q.ax);
     const float sgn = area < 0.0f ? -1.0f : 1.0f;
@@ -387,10 +411,14 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
         bool live = false;
         if (j < Fl) {
             const int jg = gid(j);
-            const Face f = load_face(a.sc.facerec, jg);
+            Face f;
+            Tri tr_unused;
+            load_face_tri<FEAT>(a.sc, jg, f, tr_unused);
             const bool dark = face_dark(f);
             live = !dark;
-            if (!TILED && dark && visout) {
+            if (!TILED && visout) {
+                // every word starts from zero: dark faces stay there, live faces receive their bits from the trace
+                // (stored whole, or OR-ed in pieces when a face's strata straddle two wave items)
                 uint32_t* visp = visout + ((size_t)l * a.vis_words) * F + j;
                 for (int wi = 0; wi < a.vis_words; ++wi) visp[(size_t)wi * F] = 0u;
             }
@@ -411,6 +439,17 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
         for (int b = 0; b < nblocks; ++b) run += (uint32_t)__popcll(s_mask[b]);
         s_ctl[3] = (int)run;
     }
+    // A triangle that lies deeper than every depth bound under its bounding box enters no cell: skip it before the
+    // edge functions are set up.  (The far side of the object is behind the live faces of its cells, and Morton
+    // order keeps such triangles together -- whole waves leave here.)
+    auto reachable = [&](uint32_t zn) {
+        return [&, zn](int cx0, int cx1, int cy0, int cy1) -> bool {
+            bool any = false;
+            for (int yy = cy0 >> 1; yy <= (cy1 >> 1); ++yy)
+                for (int xx = cx0 >> 1; xx <= (cx1 >> 1); ++xx) any = any || zn <= s_zc[yy * R2 + xx];
+            return any;
+        };
+    };
     // ---- count + scan; if the cell lists do not fit the entry capacity, coarsen the grid (x 3/4, up to
     // twice) and count again: fewer cells per triangle, longer lists.  That costs one more depth-bound and
     // counting pass (~15 % of the kernel) where the alternative is the big-LDS relaunch at half the occupancy.
@@ -443,7 +482,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 const uint32_t zn = __float_as_uint(fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f));
                 raster_tri(g, q, [&](int xx, int yy) {
                     if (zn <= s_zc[(yy >> 1) * R2 + (xx >> 1)]) atomicAdd(&s_cell[yy * R + xx], 1u);
-                });
+                }, reachable(zn));
             }
         }
         __syncthreads();
@@ -511,7 +550,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     uint32_t pos = atomicAdd(&s_cell[yy * R + xx], 1u);
                     s_ent[pos] = make_entry(g, bb, xx, yy, zq, jl);
                 }
-            });
+            }, reachable(zn));
             if (fill_buckets && ((s_mask[jl >> 6] >> (jl & 63)) & 1ull)) {
                 const int cx0 = cell_coord(bb.x0, g.gx0, g.inv_cw, R), cx1 = cell_coord(bb.x1, g.gx0, g.inv_cw, R);
                 const int cy0 = cell_coord(bb.y0, g.gy0, g.inv_ch, R), cy1 = cell_coord(bb.y1, g.gy0, g.inv_ch, R);
@@ -579,23 +618,34 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     __syncthreads();
     FWD_STAMP();   // 4: bucketed live list
     const int n_live = compact ? s_ctl[3] : Fl;
-    const int live_blocks = (n_live + 63) >> 6;
 
-    // ---- trace + histogram: dense lanes over the live faces ----------------------------------------
-    // Per sample the 64 rays of a wave are handled in two wave-synchronous stages:
+    // ---- trace + histogram: one RAY per lane ---------------------------------------------------------
+    // The rays of a source are the (live face, stratum) pairs r = li * spt + s in the order of the bucketed
+    // live list; a wave takes 64 consecutive rays through an LDS ticket.  (Round 1 gave every lane a FACE and
+    // looped over its strata: the face's vertices, edges and normal then stay live across the walk and the
+    // exact-test rounds of every stratum -- 128 VGPRs with 17 spilled and scratch reloads inside the sample
+    // loop.  With one ray per lane the face data is dead once the ray exists.)  Per item the 64 rays go through
+    // two wave-synchronous stages:
     //  (1) filter: every lane walks its own cell list in lockstep with LDS-only work (entry index +
     //      quantised projected box) and appends the survivors, as (owner lane, triangle) pairs, to a
     //      wave-private LDS queue (ballot + prefix rank);
-    //  (2) exact test: whenever 64 pairs are queued (and at the end) each lane takes ONE pair, pulls
-    //      the owner's ray through ds_bpermute, gathers the 48-byte record and runs the triangle
+    //  (2) exact test: whenever kRound pairs are queued (and at the end) each lane takes its share of the
+    //      pairs, pulls the owner's ray through ds_bpermute, gathers the 48-byte record and runs the triangle
     //      test; hits are OR-ed into the wave's occlusion mask.
-    // The kernel is VALU-issue bound and cell lists have a heavy tail (mean 17, wave-max 36
-    // entries; 5.7 exact tests per ray at 22 % lane occupancy when done in place), so the expensive
-    // stage must run on dense lanes and must not wait for the longest list.
+    // The kernel is VALU-issue bound and cell lists have a heavy tail, so the expensive stage must run on
+    // dense lanes and must not wait for the longest list.
     const uint64_t lg = (uint64_t)(a.src.source_offset + l);
     const int spt = a.sp.spt;
     const float lb = a.sp.lb, ub = a.sp.ub, res = a.sp.res;
     double* grow = a.rows ? a.rows + (size_t)l * nbins : nullptr;
+    const uint32_t n_rays = (uint32_t)n_live * (uint32_t)spt;       // <= num_samples + F
+#ifdef NLOS_DIAG_NO_TRACE          // diagnostic builds only (tools/ab_pmc.sh): cost of the build phases alone
+    const int n_items = 0;
+#else
+    const int n_items = (int)((n_rays + 63u) >> 6);
+#endif
+    const uint64_t kbase0 = lg * (uint64_t)F;
+    const double inv_spt = 1.0 / (double)spt;
 #ifdef NLOS_FWD_STAMPS
     unsigned long long c_rays = 0, c_pairs = 0, c_iters = 0, c_mt = 0, c_mtw = 0;   // diagnostic build only
     long long tg = 0, ts = 0, tx = 0, th = 0, tmark = 0;
@@ -609,40 +659,42 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     uint32_t* wocc = s_queue + nwaves * kQueueCap + wave * 2;  // this wave's 64-bit occlusion mask
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    for (;;) {
-        const int b = wave_ticket(&s_ctl[0]);
-        if (b >= live_blocks) break;
-        const int li = (b << 6) + lane;
-        bool has_face = li < n_live;
-        const int j = has_face ? (compact ? (int)g_live[li] : li) : 0;     // index within this workgroup's face set
-        const int jg = gid(j);                                              // sorted-face index
-        const Face f = load_face(a.sc.facerec, jg);
-        if (!compact && has_face) has_face = !face_dark(f);                 // (the block masks are gone: the queue reuses their LDS)
-        if (TILED && !compact && has_face && frame_ok) {
-            // overflowed subset: every face is visited, most of them lie outside this tile
-            const Proj2 q = project_tri(o, f.p0, f.p1, f.p2);
-            const float cwm = __builtin_amdgcn_rcpf(g.inv_cw) * (1.0f + 4e-3f), chm = __builtin_amdgcn_rcpf(g.inv_ch) * (1.0f + 4e-3f);
-            has_face = fmaxf(fmaxf(q.ax, q.bx), q.cx) >= g.gx0 - 4e-3f * cwm && fminf(fminf(q.ax, q.bx), q.cx) <= g.gx0 + (float)R * cwm &&
-                       fmaxf(fmaxf(q.ay, q.by), q.cy) >= g.gy0 - 4e-3f * chm && fminf(fminf(q.ay, q.by), q.cy) <= g.gy0 + (float)R * chm;
-        }
-        uint32_t* visp = (visout && has_face) ? visout + ((size_t)l * a.vis_words) * F + jg : nullptr;
-        const uint32_t* visb = (NCM == 2 && has_face) ? a.vis2 + ((size_t)l * a.vis_words) * F + jg : nullptr;
-        const Tri tr = load_tri(a.sc.tris, jg);
-        const uint64_t kbase = (lg * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
-        uint32_t word = 0, word_b = 0;
-        double inten = 0.0;
-        for (int s = 0; s < spt; ++s) {
+    // GRID (workgroup-uniform): occlusion through the cell lists; otherwise (scene not strictly in front of the
+    // wall point, or lists that fit nowhere) every ray runs the stackless BVH query.  Two instances of the loop,
+    // so that the traversal's registers and masks are not live in the grid loop.  With a valid frame every
+    // vertex lies in front of the wall point, hence dir.z > 0 for every ray of the grid loop.
+    auto trace = [&](auto grid_c) {
+        constexpr bool GRID = decltype(grid_c)::value;
+        for (;;) {
+            const int b = wave_ticket(&s_ctl[0]);
+            if (b >= n_items) break;
             TMARK();
+            const uint32_t r = ((uint32_t)b << 6) + (uint32_t)lane;
+            bool has_ray = r < n_rays;
+            const uint32_t li = has_ray ? r / (uint32_t)spt : 0u;
+            const int s = has_ray ? (int)(r - li * (uint32_t)spt) : 0;
+            const int j = compact ? (int)g_live[li] : (int)li;              // index within this workgroup's face set
+            const int jg = gid(j);                                          // sorted-face index
+            Face f;
+            Tri tr;
+            load_face_tri<FEAT>(a.sc, jg, f, tr);
+            if (!compact && has_ray) has_ray = !face_dark(f);               // (the block masks are gone: the queue reuses their LDS)
+            if (TILED && !compact && has_ray && frame_ok) {
+                // overflowed subset: every face is visited, most of them lie outside this tile
+                const Proj2 q = project_tri(o, f.p0, f.p1, f.p2);
+                const float cwm = __builtin_amdgcn_rcpf(g.inv_cw) * (1.0f + 4e-3f), chm = __builtin_amdgcn_rcpf(g.inv_ch) * (1.0f + 4e-3f);
+                has_ray = fmaxf(fmaxf(q.ax, q.bx), q.cx) >= g.gx0 - 4e-3f * cwm && fminf(fminf(q.ax, q.bx), q.cx) <= g.gx0 + (float)R * cwm &&
+                          fmaxf(fmaxf(q.ay, q.by), q.cy) >= g.gy0 - 4e-3f * chm && fminf(fminf(q.ay, q.by), q.cy) <= g.gy0 + (float)R * chm;
+            }
+            const uint64_t key = (kbase0 + (uint64_t)f.fid) * (uint64_t)spt + (uint64_t)s;
             V3 dir = mk(0.0f, 0.0f, 1.0f);
             float t_self = 0.0f, val = 0.0f;
             int bin = -1;
-            bool ok = has_face;
-            if (NCM == 2 && (s & 31) == 0 && has_face) word_b = visb[(size_t)(s >> 5) * F];
+            bool ok = has_ray;
             if (NCM == 0) {
                 Geo gg;
                 if (ok)
-                    ok = sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, lb, ub, a.sc.vertex_normal,
-                                          a.sc.albedo, gg, t_self);
+                    ok = sample_geo<FEAT>(f, tr, o, a.sp.seed, key, lb, ub, a.sc.vertex_normal, a.sc.albedo, gg, t_self);
                 if (ok) {
                     float ff = -dot(gg.n, gg.dir) * dot(on, gg.dir) / gg.h / gg.h;
                     if (a.sp.clamp) {
@@ -658,7 +710,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 // sensor leg only: is the stratified point the closest hit seen from the sensor?
                 if (ok) {
                     float S, T;
-                    sample_st(a.sp.seed, kbase + (uint64_t)s, S, T);
+                    sample_st(a.sp.seed, key, S, T);
                     const float sq = sqrtf(T);
                     const V3 p = bary(1 - sq, f.p0, (1 - S) * sq, f.p1, S * sq, f.p2);
                     const V3 d = p - o;
@@ -672,9 +724,9 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 GeoNC gc;
                 float t_b;
                 if (ok)
-                    ok = sample_geo_nc<FEAT>(f, tr, o, ob, a.sp.seed, kbase + (uint64_t)s, lb, ub, a.sc.vertex_normal,
-                                             a.sc.albedo, gc, t_self, t_b);
+                    ok = sample_geo_nc<FEAT>(f, tr, o, ob, a.sp.seed, key, lb, ub, a.sc.vertex_normal, a.sc.albedo, gc, t_self, t_b);
                 if (ok) {
+                    const uint32_t word_b = a.vis2[((size_t)l * a.vis_words + (size_t)(s >> 5)) * F + jg];
                     const float ffa = emax0(-dot(gc.n, gc.dirA) * dot(on, gc.dirA) / gc.d1 / gc.d1);
                     const float ffb = emax0(-dot(gc.n, gc.dirB) * dot(onb, gc.dirB) / gc.d2 / gc.d2);
                     ok = ffa > 0.0f && ffb > 0.0f && ((word_b >> (s & 31)) & 1u);
@@ -683,6 +735,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     dir = gc.dirA;
                 }
             }
+            const int fid = f.fid;
             if (TILED && ok && frame_ok) {
                 // the tile that owns this sample: from the source's global frame, identical in every workgroup
                 const float izo = __builtin_amdgcn_rcpf(dir.z);
@@ -691,134 +744,153 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 ok = dir.z > 0.0f ? (ti == tile_x && tj == tile_y) : tile == 0;
             }
             if (!ok) dir = mk(0.0f, 0.0f, 1.0f);
-            const bool grid_ray = ok && use_grid && dir.z > 0.0f;
-            if (ok && !grid_ray)
-                ok = !occluded(a.sc.nodes, a.sc.n_nodes, a.sc.tris, a.sc.face_id, o, dir, t_self, jg, f.fid);
+            if (!GRID && ok)
+                ok = !occluded(a.sc.nodes, a.sc.n_nodes, a.sc.tris, a.sc.face_id, o, dir, t_self, jg, fid);
 
-            // ---- stage 1 + 2 (wave-synchronous; every lane takes part) ----
-            uint32_t e = 0, e1 = 0, rmask = 0, rlim = 0;
-            if (grid_ray) {
-                const float iz = __builtin_amdgcn_rcpf(dir.z);   // lookups only: 1-ulp rcp is fine
-                const float ux = (dir.x * iz - g.gx0) * g.inv_cw, uy = (dir.y * iz - g.gy0) * g.inv_ch;
-                const int cxx = min(max((int)floorf(ux), 0), R - 1), cyy = min(max((int)floorf(uy), 0), R - 1);
-                const int sx = min(max((int)floorf((ux - (float)cxx) * (float)kSub), 0), kSub - 1);
-                const int sy = min(max((int)floorf((uy - (float)cyy) * (float)kSub), 0), kSub - 1);
-                rmask = (1u << (IB + sx)) | (1u << (IB + kSub + sy));
-                // depth level of the own-face hit, rounded up: anything quantised deeper cannot occlude
-                const float zs = t_self * dir.z;
-                const uint32_t rq = (uint32_t)min(max((int)floorf((zs * 1.00002f - g.z0) * g.inv_qz) + 1, 0), g.zmax);
-                rlim = (rq << (IB + 2 * kSub)) | ((1u << (IB + 2 * kSub)) - 1u);
-                const int c = cyy * R + cxx;
-                e1 = s_cell[c];
-                e = c > 0 ? s_cell[c - 1] : 0u;
-            }
-            if (lane < 2) wocc[lane] = 0u;
-            TACC(tg);
-            int qn = 0;                                        // wave-uniform
-            auto exact_round = [&](int n) {
-#ifdef NLOS_FWD_STAMPS
-                if (lane == 0) c_mtw += 1;
+            if (GRID) {
+                // ---- stage 1 + 2 (wave-synchronous; every lane takes part) ----
+                const bool grid_ray = ok;
+                uint32_t e = 0, e1 = 0, rmask = 0, rlim = 0;
+                if (grid_ray) {
+                    const float iz = __builtin_amdgcn_rcpf(dir.z);   // lookups only: 1-ulp rcp is fine
+                    const float ux = (dir.x * iz - g.gx0) * g.inv_cw, uy = (dir.y * iz - g.gy0) * g.inv_ch;
+                    const int cxx = min(max((int)floorf(ux), 0), R - 1), cyy = min(max((int)floorf(uy), 0), R - 1);
+                    const int sx = min(max((int)floorf((ux - (float)cxx) * (float)kSub), 0), kSub - 1);
+                    const int sy = min(max((int)floorf((uy - (float)cyy) * (float)kSub), 0), kSub - 1);
+                    rmask = (1u << (IB + sx)) | (1u << (IB + kSub + sy));
+                    // depth level of the own-face hit, rounded up: anything quantised deeper cannot occlude
+                    const float zs = t_self * dir.z;
+                    const uint32_t rq = (uint32_t)min(max((int)floorf((zs * 1.00002f - g.z0) * g.inv_qz) + 1, 0), g.zmax);
+                    rlim = (rq << (IB + 2 * kSub)) | ((1u << (IB + 2 * kSub)) - 1u);
+                    const int c = cyy * R + cxx;
+                    e1 = s_cell[c];
+                    e = c > 0 ? s_cell[c - 1] : 0u;
+#ifdef NLOS_DIAG_NO_WALK           // diagnostic builds only
+                    e = e1;
 #endif
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int h = 0; h < kRound / 64; ++h) {
-                    const int qi = lane + 64 * h;
-                    const uint32_t pr = wq[qi < n ? qi : 0];
-                    const int owner = (int)(pr >> 16), k = (int)(pr & 0xFFFFu);
-                    const V3 od = mk(__shfl(dir.x, owner), __shfl(dir.y, owner), __shfl(dir.z, owner));
-                    const float ot = __shfl(t_self, owner);
-                    const int ofid = __shfl(f.fid, owner);
-                    if (qi < n) {
-                        const int kg = gid(k);
-                        const Tri tk = load_tri(a.sc.tris, kg);
-                        if (tri_occludes(tk, o, od, ot, ofid, a.sc.face_id, kg))
-                            atomicOr(&wocc[owner >> 5], 1u << (owner & 31));
-                    }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            };
-            // lockstep filter walk (LDS only): entry index + packed box/depth word.  (A fully
-            // flattened walk -- pairs spread evenly over the lanes with a prefix-sum owner search --
-            // halves the iterations but its dependent ds_bpermute chain makes it slower; measured.)
-#ifdef NLOS_FWD_STAMPS
-            if (grid_ray) c_rays += 1;
+                if (lane < 2) wocc[lane] = 0u;
+                TACC(tg);
+                int qn = 0;                                        // wave-uniform
+                auto exact_round = [&](int n) {
+#ifdef NLOS_DIAG_NO_EXACT          // diagnostic builds only: results are wrong, the counters show what the rounds cost
+                    return;
 #endif
-            constexpr uint32_t imask = (1u << IB) - 1u;
-            auto push = [&](bool pass, int k) {
-                const unsigned long long m = __ballot(pass);
-                if (m) {
-                    if (pass) wq[qn + __popcll(m & lt_mask)] = ((uint32_t)lane << 16) | (uint32_t)k;
-                    qn += __popcll(m);
-                    if (qn >= kRound) {
-                        TACC(ts);
-                        exact_round(kRound);
-                        TACC(tx);
-                        qn -= kRound;
-                        const uint32_t mv = wq[kRound + (lane < qn ? lane : 0)];       // qn < 64 left over
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane < qn) wq[lane] = mv;
-                    }
-                }
-            };
-            // kScan entries per trip: the lockstep walk pays its loop overhead (any(), branch, counters) once per
-            // trip; lists average 24 entries, so wider trips waste more slots at the end (2: 2.49 ms, 4: 2.43 ms)
-            while (__any(e < e1)) {
-                bool p[kScan];
-                int k[kScan];
+#ifdef NLOS_FWD_STAMPS
+                    if (lane == 0) c_mtw += 1;
+#endif
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int q = 0; q < kScan; ++q) { p[q] = false; k[q] = 0; }
-                if (e < e1) {
+                    for (int h = 0; h < kRound / 64; ++h) {
+                        const int qi = lane + 64 * h;
+                        const uint32_t pr = wq[qi < n ? qi : 0];
+                        const int owner = (int)(pr >> 16), k = (int)(pr & 0xFFFFu);
+                        const V3 od = mk(__shfl(dir.x, owner), __shfl(dir.y, owner), __shfl(dir.z, owner));
+                        const float ot = __shfl(t_self, owner);
+                        const int ofid = __shfl(fid, owner);
+                        if (qi < n) {
+                            const int kg = gid(k);
+                            const Tri tk = load_tri(a.sc.tris, kg);
+                            if (tri_occludes(tk, o, od, ot, ofid, a.sc.face_id, kg))
+                                atomicOr(&wocc[owner >> 5], 1u << (owner & 31));
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                };
+                // lockstep filter walk (LDS only): entry index + packed box/depth word.  (A fully
+                // flattened walk -- pairs spread evenly over the lanes with a prefix-sum owner search --
+                // halves the iterations but its dependent ds_bpermute chain makes it slower; measured.)
+#ifdef NLOS_FWD_STAMPS
+                if (grid_ray) c_rays += 1;
+#endif
+                constexpr uint32_t imask = (1u << IB) - 1u;
+                auto push = [&](bool pass, uint32_t w) {
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+                    if (m) {
+                        if (pass) wq[qn + __popcll(m & lt_mask)] = ((uint32_t)lane << 16) | (w & imask);
+                        qn += __popcll(m);
+                        if (qn >= kRound) {
+                            TACC(ts);
+                            exact_round(kRound);
+                            TACC(tx);
+                            qn -= kRound;
+                            const uint32_t mv = wq[kRound + (lane < qn ? lane : 0)];       // qn < 64 left over
+                            __builtin_amdgcn_wave_barrier();
+                            if (lane < qn) wq[lane] = mv;
+                        }
+                    }
+                };
+                // The filter on one word: with x = w ^ j (the index field of x is zero for the ray's own face)
+                //   x <= rlim                       <=>  w <= rlim   (rlim's low bits are all ones: only the depth field decides)
+                //   (x & (rmask | imask)) > rmask   <=>  both mask bits of the ray are set AND the index field is not zero
+                // (the two bits of rmask lie above the index field, so a word that misses one of them stays below rmask
+                // whatever its index) -- four VALU operations per entry instead of six.
+                const uint32_t jx = (uint32_t)j, m2 = rmask | imask;
+                // kScan entries per trip: the lockstep walk pays its loop overhead (any(), branch, counters) once per
+                // trip; lists average 24 entries, so wider trips waste more slots at the end (2: 2.49 ms, 4: 2.43 ms)
+                while (__any(e < e1)) {
+                    // every lane reads its next kScan words (finished lanes re-read the slots behind their list and
+                    // fail the range term): no divergent region, so the ballots below are the compare masks themselves
+                    const uint32_t rem = e < e1 ? e1 - e : 0u;
+                    bool p[kScan];
+                    uint32_t w[kScan];
 #pragma unroll
                     for (int q = 0; q < kScan; ++q) {
-                        const uint32_t w = s_ent[e + q];
-                        k[q] = (int)(w & imask);
-                        p[q] = (e + q < e1) & (w <= rlim) & ((w & rmask) == rmask) & (k[q] != j);
+                        w[q] = s_ent[e + q];
+                        const uint32_t x = w[q] ^ jx;
+                        p[q] = ((uint32_t)q < rem) & (x <= rlim) & ((x & m2) > rmask);
                     }
 #ifdef NLOS_FWD_STAMPS
-                    if (grid_ray) c_pairs += min(kScan, (int)(e1 - e));
+                    if (grid_ray) c_pairs += min((uint32_t)kScan, rem);
+                    if (lane == 0) c_iters += 1;
+#pragma unroll
+                    for (int q = 0; q < kScan; ++q) if (p[q]) c_mt += 1;
 #endif
-                    e += kScan;
+                    e += min((uint32_t)kScan, rem);
+#pragma unroll
+                    for (int q = 0; q < kScan; ++q) push(p[q], w[q]);
                 }
-#ifdef NLOS_FWD_STAMPS
-                if (lane == 0) c_iters += 1;
-#pragma unroll
-                for (int q = 0; q < kScan; ++q) if (p[q]) c_mt += 1;
-#endif
-#pragma unroll
-                for (int q = 0; q < kScan; ++q) push(p[q], k[q]);
+                TACC(ts);
+                if (qn > 0) exact_round(qn);
+                TACC(tx);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (grid_ray) ok = ((wocc[lane >> 5] >> (lane & 31)) & 1u) == 0u;
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                TACC(tg);
             }
-            TACC(ts);
-            if (qn > 0) exact_round(qn);
-            TACC(tx);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (grid_ray) ok = ((wocc[lane >> 5] >> (lane & 31)) & 1u) == 0u;
-            __builtin_amdgcn_wave_barrier();
 
-            if (ok) {
-                word |= 1u << (s & 31);
-                if (NCM == 1) {
-                    // visibility only
-                } else if (a.mode_intensity) {
-                    inten += (double)val / (double)spt;
-                } else if (bin >= 0 && bin < nbins) {
-                    double cc = (double)val / (double)spt;
+            if (ok && NCM != 1) {
+                // (double)val / spt as the reference bins it, up to the rounding of 1 / spt (below the order-of-
+                // summation noise of the fp64 rows)
+                const double cc = (double)val * inv_spt;
+                if (a.mode_intensity) unsafeAtomicAdd(&a.intensity[fid], cc);
+                else if (bin >= 0 && bin < nbins) {
                     if (rows_in_lds) unsafeAtomicAdd(&s_row[bin], cc);
                     else unsafeAtomicAdd(&grow[bin], cc);
                 }
             }
-            if ((s & 31) == 31 || s == spt - 1) {
-                if (visp) {
-                    if (!TILED) visp[(size_t)(s >> 5) * F] = word;
-                    else if (word) atomicOr(&visp[(size_t)(s >> 5) * F], word);   // a face may straddle tiles
+            if (visout) {
+                // accepted-sample bits: the strata of a (face, word) that this wave holds sit in consecutive lanes;
+                // the first of them writes the piece.  A word that lies completely inside the wave is stored (its
+                // only writer); a face that straddles two items -- or tiles -- ORs its pieces into the zeroed word.
+                const unsigned long long acc = __ballot(ok);
+                if (has_ray && (lane == 0 || (s & 31) == 0)) {
+                    const int in_word = min(spt - s, 32 - (s & 31));                  // strata left in this word
+                    const int cnt = min(in_word, 64 - lane);                          // ... of which this wave holds
+                    const uint32_t bits = (uint32_t)((acc >> lane) & ((1ull << cnt) - 1ull));
+                    uint32_t* wp = visout + ((size_t)l * a.vis_words + (size_t)(s >> 5)) * F + jg;
+                    if (!TILED && (s & 31) == 0 && cnt == in_word) *wp = bits;
+                    else if (bits) atomicOr(wp, bits << (s & 31));
                 }
-                word = 0;
             }
             TACC(th);
         }
-        if (a.mode_intensity && has_face && inten != 0.0) unsafeAtomicAdd(&a.intensity[f.fid], inten);
-    }
+    };
+    if (use_grid) trace(std::true_type{});
+    else trace(std::false_type{});
 #ifdef NLOS_FWD_STAMPS
     if (a.dbg) {   // diagnostic build only: work counters -> a.dbg[8..12]
         atomicAdd((unsigned long long*)&a.dbg[8], c_rays);
