@@ -119,15 +119,21 @@ __device__ __forceinline__ uint32_t make_entry(const GridView& g, const BBoxF& b
 
 // conservative rasterisation of a projected triangle: fn(xx, yy) for every overlapped cell.  `pre(cx0, cx1, cy0, cy1)`
 // sees the cell range of the bounding box first and may drop the triangle before the edge functions are set up.
+// Cells are `cw x ch` wide from (gx0, gy0); `Rx` cells per side.  An edge function is evaluated at the corner of
+// the cell that lies deepest inside the half-plane and stepped from cell to cell by one addition: its drift over a
+// bounding box (a few ulps of the largest term) is three orders of magnitude below the slack t_i, which is sized
+// for the rounding of the projection.  (Round 1 re-evaluated the three edge functions from the cell coordinates
+// in every cell: 30 VALU operations per cell against 7 here, and the build phases were 41 % of the kernel.)
 struct RasterAll { __device__ __forceinline__ bool operator()(int, int, int, int) const { return true; } };
 template <class Fn, class Pre = RasterAll>
-__device__ __forceinline__ void raster_tri(const GridView& g, const Proj2& q, Fn fn, Pre pre = Pre()) {
-    const float cw = __builtin_amdgcn_rcpf(g.inv_cw), ch = __builtin_amdgcn_rcpf(g.inv_ch);
+__device__ __forceinline__ void raster_cells(float gx0, float gy0, float inv_cw, float inv_ch, int Rx, const Proj2& q, Fn fn,
+                                             Pre pre = Pre()) {
+    const float cw = __builtin_amdgcn_rcpf(inv_cw), ch = __builtin_amdgcn_rcpf(inv_ch);
     const float mgx = 1e-3f * cw, mgy = 1e-3f * ch;          // >> fp32 rounding of the projection
-    const int cx0 = cell_coord(fminf(fminf(q.ax, q.bx), q.cx) - mgx, g.gx0, g.inv_cw, g.R);
-    const int cx1 = cell_coord(fmaxf(fmaxf(q.ax, q.bx), q.cx) + mgx, g.gx0, g.inv_cw, g.R);
-    const int cy0 = cell_coord(fminf(fminf(q.ay, q.by), q.cy) - mgy, g.gy0, g.inv_ch, g.R);
-    const int cy1 = cell_coord(fmaxf(fmaxf(q.ay, q.by), q.cy) + mgy, g.gy0, g.inv_ch, g.R);
+    const int cx0 = cell_coord(fminf(fminf(q.ax, q.bx), q.cx) - mgx, gx0, inv_cw, Rx);
+    const int cx1 = cell_coord(fmaxf(fmaxf(q.ax, q.bx), q.cx) + mgx, gx0, inv_cw, Rx);
+    const int cy0 = cell_coord(fminf(fminf(q.ay, q.by), q.cy) - mgy, gy0, inv_ch, Rx);
+    const int cy1 = cell_coord(fmaxf(fmaxf(q.ay, q.by), q.cy) + mgy, gy0, inv_ch, Rx);
     if (!pre(cx0, cx1, cy0, cy1)) return;
     // edge functions, oriented so that the inside is >= 0
     const float area = (q.bx - q.ax) * (q.cy - q.ay) - (q.by - q.ay) * (q.cx - q.ax);
@@ -139,19 +145,31 @@ __device__ __forceinline__ void raster_tri(const GridView& g, const Proj2& q, Fn
     const float t0 = 2e-3f * (fabsf(A0) * cw + fabsf(B0) * ch);
     const float t1 = 2e-3f * (fabsf(A1) * cw + fabsf(B1) * ch);
     const float t2 = 2e-3f * (fabsf(A2) * cw + fabsf(B2) * ch);
+    // value at the first cell's inside-most corner (+ slack), and the steps per cell
+    const float x00 = gx0 + (float)cx0 * cw, y00 = gy0 + (float)cy0 * ch;
+    float E0 = A0 * (x00 + (A0 > 0 ? cw : 0.0f)) + B0 * (y00 + (B0 > 0 ? ch : 0.0f)) + (C0 + t0);
+    float E1 = A1 * (x00 + (A1 > 0 ? cw : 0.0f)) + B1 * (y00 + (B1 > 0 ? ch : 0.0f)) + (C1 + t1);
+    float E2 = A2 * (x00 + (A2 > 0 ? cw : 0.0f)) + B2 * (y00 + (B2 > 0 ? ch : 0.0f)) + (C2 + t2);
+    const float ax0 = A0 * cw, ax1 = A1 * cw, ax2 = A2 * cw;
+    const float by0 = B0 * ch, by1 = B1 * ch, by2 = B2 * ch;
     for (int yy = cy0; yy <= cy1; ++yy) {
-        const float y0 = g.gy0 + (float)yy * ch, y1 = y0 + ch;
+        float r0 = E0, r1 = E1, r2 = E2;
         for (int xx = cx0; xx <= cx1; ++xx) {
-            const float x0 = g.gx0 + (float)xx * cw, x1 = x0 + cw;
-            bool in = true;
-            if (!thin) {
-                in = (A0 * (A0 > 0 ? x1 : x0) + B0 * (B0 > 0 ? y1 : y0) + C0 >= -t0) &&
-                     (A1 * (A1 > 0 ? x1 : x0) + B1 * (B1 > 0 ? y1 : y0) + C1 >= -t1) &&
-                     (A2 * (A2 > 0 ? x1 : x0) + B2 * (B2 > 0 ? y1 : y0) + C2 >= -t2);
-            }
-            if (in) fn(xx, yy);
+            if (thin | ((r0 >= 0.0f) & (r1 >= 0.0f) & (r2 >= 0.0f))) fn(xx, yy);
+            r0 += ax0; r1 += ax1; r2 += ax2;
         }
+        E0 += by0; E1 += by1; E2 += by2;
     }
+}
+template <class Fn, class Pre = RasterAll>
+__device__ __forceinline__ void raster_tri(const GridView& g, const Proj2& q, Fn fn, Pre pre = Pre()) {
+    raster_cells(g.gx0, g.gy0, g.inv_cw, g.inv_ch, g.R, q, fn, pre);
+}
+// the same on the coarse map of the depth bounds (one cell = 2 x 2 cells of the grid, R2 = (R + 1) / 2 per side): a
+// coarse cell is touched iff one of its four cells is (up to the slack), at a quarter of the cells
+template <class Fn>
+__device__ __forceinline__ void raster_tri_coarse(const GridView& g, int R2, const Proj2& q, Fn fn) {
+    raster_cells(g.gx0, g.gy0, 0.5f * g.inv_cw, 0.5f * g.inv_ch, R2, q, fn);
 }
 
 // Slope-space frame of a source: bounding rectangle of the projection of the BVH's (padded) root box.
@@ -274,6 +292,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     uint8_t* s_len8 = reinterpret_cast<uint8_t*>(s_mask + mask_blocks);
     const bool len_ok = (((R2 * R2 + 1) & ~1) + 2 * mask_blocks) * 4 + ncell <= union_words * 4;
     uint16_t* g_live = a.live + (size_t)blockIdx.x * (TILED ? a.tile_cap : F);
+    uint32_t* g_cov = a.cov + (size_t)blockIdx.x * (TILED ? a.tile_cap : F);     // per-triangle cell coverage, count -> fill pass
     uint32_t* tl = TILED ? a.tile_list + (size_t)blockIdx.x * a.tile_cap : nullptr;
 
     const int l = TILED ? (int)(blockIdx.x / (unsigned)ntiles) : (int)blockIdx.x;
@@ -426,7 +445,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 const float zfar = fmaxf(fmaxf(f.p0.z, f.p1.z), f.p2.z) - o.z;
                 const uint32_t zb = __float_as_uint(fmaxf(zfar, 0.0f) * 1.0001f + 1e-30f);
                 const Proj2 q = project_tri(o, f.p0, f.p1, f.p2);
-                raster_tri(g, q, [&](int xx, int yy) { atomicMax(&s_zc[(yy >> 1) * R2 + (xx >> 1)], zb); });
+                raster_tri_coarse(g, R2, q, [&](int cx, int cy) { atomicMax(&s_zc[cy * R2 + cx], zb); });
             }
         }
         const unsigned long long m = __ballot(live);
@@ -468,7 +487,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     const float zfar = fmaxf(fmaxf(q0.z, q1.y), q2.x) - o.z;
                     const uint32_t zb = __float_as_uint(fmaxf(zfar, 0.0f) * 1.0001f + 1e-30f);
                     const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
-                    raster_tri(g, q, [&](int xx, int yy) { atomicMax(&s_zc[(yy >> 1) * R2 + (xx >> 1)], zb); });
+                    raster_tri_coarse(g, R2, q, [&](int cx, int cy) { atomicMax(&s_zc[cy * R2 + cx], zb); });
                 }
             }
             __syncthreads();
@@ -480,9 +499,23 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
                 const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
                 const uint32_t zn = __float_as_uint(fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f));
+                // the cells the triangle enters are remembered for the fill pass (one word per triangle in global
+                // scratch): bounding boxes of up to 4 x 4 cells as a bit mask, larger ones are rasterised again
+                int bx0 = 0, by0 = 0;
+                bool big = false, reach = false;
+                uint32_t cv = 0u;
                 raster_tri(g, q, [&](int xx, int yy) {
-                    if (zn <= s_zc[(yy >> 1) * R2 + (xx >> 1)]) atomicAdd(&s_cell[yy * R + xx], 1u);
-                }, reachable(zn));
+                    if (zn <= s_zc[(yy >> 1) * R2 + (xx >> 1)]) {
+                        atomicAdd(&s_cell[yy * R + xx], 1u);
+                        cv |= 1u << ((((yy - by0) & 3) << 2) + ((xx - bx0) & 3));
+                    }
+                }, [&](int cx0, int cx1, int cy0, int cy1) -> bool {
+                    bx0 = cx0; by0 = cy0;
+                    big = cx1 - cx0 > 3 || cy1 - cy0 > 3;
+                    reach = reachable(zn)(cx0, cx1, cy0, cy1);
+                    return reach;
+                });
+                g_cov[jl] = !reach ? 0u : big ? 0x80000000u : (((uint32_t)bx0 << 24) | ((uint32_t)by0 << 17) | cv);
             }
         }
         __syncthreads();
@@ -536,28 +569,45 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     if (frame_ok && s_ctl[1] == 0) {
         int it = 0;
         for (int jl = tid; jl < Fl; jl += NT, ++it) {
-            const int j = gid(jl);
-            const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
-            const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
-            const float zmin_rel = fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f);
-            const uint32_t zn = __float_as_uint(zmin_rel);
-            const uint32_t zq = (uint32_t)min(max((int)floorf((zmin_rel - g.z0) * g.inv_qz) - 1, 0), g.zmax);
-            BBoxF bb;
-            bb.x0 = fminf(fminf(q.ax, q.bx), q.cx); bb.x1 = fmaxf(fmaxf(q.ax, q.bx), q.cx);
-            bb.y0 = fminf(fminf(q.ay, q.by), q.cy); bb.y1 = fmaxf(fmaxf(q.ay, q.by), q.cy);
-            raster_tri(g, q, [&](int xx, int yy) {
-                if (zn <= s_zc[(yy >> 1) * R2 + (xx >> 1)]) {
-                    uint32_t pos = atomicAdd(&s_cell[yy * R + xx], 1u);
-                    s_ent[pos] = make_entry(g, bb, xx, yy, zq, jl);
+            // what the counting pass found: nothing to enter (about half of the triangles: the far side of the
+            // object), a mask of up to 4 x 4 cells, or a large bounding box that is rasterised again
+            const uint32_t cov = g_cov[jl];
+            const bool counts_as_live = fill_buckets && ((s_mask[jl >> 6] >> (jl & 63)) & 1ull);
+            if ((cov & 0x8000FFFFu) == 0u && !counts_as_live) continue;
+            uint32_t nmax = 0u;                              // longest list among the cells the triangle enters
+            if (cov & 0x8000FFFFu) {
+                const int j = gid(jl);
+                const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
+                const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
+                const float zmin_rel = fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f);
+                const uint32_t zn = __float_as_uint(zmin_rel);
+                const uint32_t zq = (uint32_t)min(max((int)floorf((zmin_rel - g.z0) * g.inv_qz) - 1, 0), g.zmax);
+                BBoxF bb;
+                bb.x0 = fminf(fminf(q.ax, q.bx), q.cx); bb.x1 = fmaxf(fmaxf(q.ax, q.bx), q.cx);
+                bb.y0 = fminf(fminf(q.ay, q.by), q.cy); bb.y1 = fmaxf(fmaxf(q.ay, q.by), q.cy);
+                if (cov & 0x80000000u) {
+                    raster_tri(g, q, [&](int xx, int yy) {
+                        if (zn <= s_zc[(yy >> 1) * R2 + (xx >> 1)]) {
+                            const int c = yy * R + xx;
+                            uint32_t pos = atomicAdd(&s_cell[c], 1u);
+                            s_ent[pos] = make_entry(g, bb, xx, yy, zq, jl);
+                            if (len_ok) nmax = max(nmax, (uint32_t)s_len8[c]);
+                        }
+                    }, reachable(zn));
+                } else {
+                    const int bx0 = (int)((cov >> 24) & 127u), by0 = (int)((cov >> 17) & 127u);
+                    for (uint32_t m = cov & 0xFFFFu; m; m &= m - 1u) {
+                        const int bit = __ffs((int)m) - 1;
+                        const int xx = bx0 + (bit & 3), yy = by0 + (bit >> 2);
+                        const int c = yy * R + xx;
+                        uint32_t pos = atomicAdd(&s_cell[c], 1u);
+                        s_ent[pos] = make_entry(g, bb, xx, yy, zq, jl);
+                        if (len_ok) nmax = max(nmax, (uint32_t)s_len8[c]);
+                    }
                 }
-            }, reachable(zn));
-            if (fill_buckets && ((s_mask[jl >> 6] >> (jl & 63)) & 1ull)) {
-                const int cx0 = cell_coord(bb.x0, g.gx0, g.inv_cw, R), cx1 = cell_coord(bb.x1, g.gx0, g.inv_cw, R);
-                const int cy0 = cell_coord(bb.y0, g.gy0, g.inv_ch, R), cy1 = cell_coord(bb.y1, g.gy0, g.inv_ch, R);
-                uint32_t n = 0;
-                for (int yy = cy0; yy <= cy1; ++yy)
-                    for (int xx = cx0; xx <= cx1; ++xx) n = max(n, (uint32_t)s_len8[yy * R + xx]);
-                const int bkt = (NB - 1) - (int)min(n >> NLOS_NB_SHIFT, (uint32_t)(NB - 1));   // bucket 0 = longest lists
+            }
+            if (counts_as_live) {
+                const int bkt = (NB - 1) - (int)min(nmax >> NLOS_NB_SHIFT, (uint32_t)(NB - 1));   // bucket 0 = longest lists
                 atomicAdd(&s_bkt[bkt], 1u);
                 if (it < 16) nib0 |= (unsigned long long)bkt << (4 * it);
                 else nib1 |= (unsigned long long)bkt << (4 * (it - 16));
@@ -960,7 +1010,7 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
     if (union_words < 8 * kQueueWords) union_words = 8 * kQueueWords;
     const size_t fixed = 32 + (rows_in_lds ? (size_t)a.sp.nbins * sizeof(double) : 0) + (((size_t)R * R + 2) & ~(size_t)1) * 4 +
                          ((union_words + 1) & ~(size_t)1) * 4;
-    if (fixed + 4 * 2 * (size_t)a.sc.F > kGridLdsBudget || !a.live) { note.reason = 3; return false; }   // want room for >= 2 entries per face
+    if (fixed + 4 * 2 * (size_t)a.sc.F > kGridLdsBudget || !a.live || !a.cov) { note.reason = 3; return false; }   // want room for >= 2 entries per face
     size_t cap = (kGridLdsBudget - fixed) / 4;
     const size_t lds = fixed + cap * 4;
     const size_t lds_big = 150 * 1024;
@@ -988,7 +1038,7 @@ bool forward_tiled_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t str
     LaunchNote scratch_note;
     LaunchNote& note = tl_note ? *tl_note : scratch_note;
     if (a.force_bvh) { note.reason = 1; return false; }
-    if (!a.tile_list || !a.tile_count || !a.live) return false;                      // (reason recorded by the single-workgroup launcher)
+    if (!a.tile_list || !a.tile_count || !a.live || !a.cov) return false;                      // (reason recorded by the single-workgroup launcher)
     if (a.tiles_x * a.tiles_y > 1024 || a.tiles_x < 1 || a.tiles_y < 1) { note.reason = 4; return false; }
     if ((NCM != 0) != (a.src.sensor != nullptr)) return false;
     uint32_t* const visout = NCM == 1 ? a.vis2 : a.vis;

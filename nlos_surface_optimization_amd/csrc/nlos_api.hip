@@ -92,7 +92,7 @@ struct nlos_ctx {
     // render scratch
     DevBuf vis, diff, fine, taps, rows_tmp, grad_tmp, live;
     DevBuf reg_normal, reg_area, reg_owner;
-    DevBuf vis2, tile_list, tile_count;
+    DevBuf vis2, tile_list, tile_count, cov;
     int tap_refine = -1, tap_sigma = -1; float tap_res = -1.0f; int tap_kind = -1;
     // host-pointer path staging
     DevBuf io[16];
@@ -338,7 +338,7 @@ void nlos_ctx_destroy(nlos_ctx* c) {
     DeviceGuard g(c->device);
     DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                      &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count};
+                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov};
     for (DevBuf* b : all) b->release();
     for (DevBuf& b : c->io) b.release();
     for (hipEvent_t& e : c->ring) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
@@ -351,7 +351,7 @@ int64_t nlos_ctx_scratch_bytes(const nlos_ctx* c) {
     if (!c) return 0;
     const DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                            &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count};
+                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov};
     int64_t s = 0;
     for (const DevBuf* b : all) s += (int64_t)b->cap;
     for (const DevBuf& b : c->io) s += (int64_t)b.cap;
@@ -521,6 +521,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.force_bvh = a->force_bvh == 1 ? 1 : 0;
     fa.dbg = nullptr;
     fa.live = nullptr;
+    fa.cov = nullptr;
     fa.tile_list = nullptr;
     fa.tile_count = nullptr;
     fa.retry = nullptr;
@@ -529,15 +530,17 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     int chunk_L = L > 0 ? L : 1;                       // sources per pass-1 launch
     if (nF <= tile_threshold && a->force_bvh != 1) {
         rc = c->live.ensure(sizeof(uint16_t) * (size_t)(L > 0 ? L : 1) * nF + 16);
+        if (!rc) rc = c->cov.ensure(sizeof(uint32_t) * (size_t)(L > 0 ? L : 1) * nF + 16);
         if (!rc) rc = c->tile_count.ensure(sizeof(int) * (size_t)(L > 0 ? L : 1) + 16);
         if (rc) return rc;
         fa.live = c->live.as<uint16_t>();
+        fa.cov = c->cov.as<uint32_t>();
         fa.retry = c->tile_count.as<int>();
     } else if (a->force_bvh != 1 && L > 0) {
         // tiled grid: ~3000 triangles per slope-space tile on average (small tiles leave the 512 threads idle); the densest tiles of a closed surface
         // (front + back side, several depth layers) hold up to ~4.5x the mean, and the subset capacity is bounded by
         // the 14-bit entry index (overflowing tiles fall back to the BVH query by themselves);
-        // scratch = 6 B per (source, tile, slot)
+        // scratch = 10 B per (source, tile, slot)
         static const int tile_tris = [] { const char* e = std::getenv("NLOS_TILE_TRIS"); return e && std::atoi(e) > 0 ? std::atoi(e) : 3000; }();
         const int nt = (nF + tile_tris - 1) / tile_tris;
         int side = 1;
@@ -546,7 +549,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         long long tcap = 6LL * nF / tiles + 512;
         if (tcap > 16383) tcap = 16383;
         if (a->force_bvh == 2) tcap = 64;              // diagnostic: force the subset-overflow fallback of the tiles
-        // the per-(source, tile) subsets are the largest scratch of the path (6 B per slot): bounded to 32 GB by
+        // the per-(source, tile) subsets are the largest scratch of the path (10 B per slot): bounded to 32 GB by
         // rendering the sources in chunks (NLOS_TILE_SCRATCH_MAX overrides the bound; nlos_ctx_last_path reports
         // the number of chunks)
         static const unsigned long long scratch_max = [] {
@@ -555,17 +558,19 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
             return v > 0 ? v : (32ull << 30);
         }();
         const unsigned long long per_source = (unsigned long long)tiles * (unsigned long long)tcap;
-        unsigned long long max_l = scratch_max / (6ull * per_source);
+        unsigned long long max_l = scratch_max / (10ull * per_source);
         if (max_l < 1) max_l = 1;
         if ((unsigned long long)L > max_l) chunk_L = (int)max_l;
         const unsigned long long slots = (unsigned long long)chunk_L * per_source;
         rc = c->live.ensure(sizeof(uint16_t) * slots + 16);
+        if (!rc) rc = c->cov.ensure(sizeof(uint32_t) * slots + 16);
         if (!rc) rc = c->tile_list.ensure(sizeof(uint32_t) * slots + 16);
         if (!rc) rc = c->tile_count.ensure(sizeof(int) * 2 * (size_t)chunk_L * tiles + 16);
         if (rc) return rc;
         fa.tile_count = c->tile_count.as<int>();
         fa.retry = fa.tile_count + (size_t)chunk_L * tiles;
         fa.live = c->live.as<uint16_t>();
+        fa.cov = c->cov.as<uint32_t>();
         fa.tile_list = c->tile_list.as<uint32_t>();
         fa.tiles_x = fa.tiles_y = side;
         fa.tile_cap = (int)tcap;
