@@ -169,6 +169,9 @@ def parse_args(argv=None):
                     help="strong (default): one grid x grid block of sources split over the ranks; weak: grid x grid per rank")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE config 2 (parity-run size, not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the ~13 s CPU leg (the parity gate still runs, on a small block)")
+    ap.add_argument("--prewarm-seconds", type=float, default=0.5,
+                    help="untimed steps before the W warm-up steps, for at least this long: the GPU idles while the CPU oracle "
+                         "runs the parity gate and its clocks take tens of milliseconds to come back (0 = skip)")
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="after the timed steps: a loop of at least this long, reported as sustained_ms_per_step (0 = skip)")
     ap.add_argument("--diagnostic-no-gate", action="store_true",
@@ -369,6 +372,12 @@ def run_rank(args, backend):
         backend.sync()
         return time.perf_counter() - t0
 
+    if args.prewarm_seconds > 0:
+        t_pw = time.perf_counter()
+        while time.perf_counter() - t_pw < args.prewarm_seconds:
+            for _ in range(8):
+                step()
+            backend.sync()
     for _ in range(args.warmup):
         step()
     backend.sync()

@@ -95,15 +95,25 @@ constexpr int kSub = NLOS_KSUB;   // sub-cell levels per axis
 constexpr int kIdxBits = 13;      // single-workgroup grid: 11 depth bits
 constexpr int kIdxBitsTiled = 14; // tiled grid: subsets up to 16383 triangles, 10 depth bits
 #ifndef NLOS_EXACT_ROUND
-#define NLOS_EXACT_ROUND 128
+#define NLOS_EXACT_ROUND 64
 #endif
-constexpr int kRound = NLOS_EXACT_ROUND;   // pairs per exact-test round: two per lane keep two record gathers in flight
+constexpr int kRound = NLOS_EXACT_ROUND;   // pairs per exact-test round: one per lane (two -- two record gathers in flight -- paid at four
+                                            // waves per SIMD; at six the registers are worth more: 1.91 -> 1.89 ms)
 #ifndef NLOS_SCAN_WIDTH
 #define NLOS_SCAN_WIDTH 4
 #endif
 constexpr int kScan = NLOS_SCAN_WIDTH;      // cell-list entries per trip of the lockstep walk
 constexpr int kQueueCap = kRound + 64;      // a trip appends at most 64 pairs per slot before the drain check
 constexpr int kQueueWords = kQueueCap + 2;  // + the wave's 64-bit occlusion mask
+#ifndef NLOS_GRID_NT
+#define NLOS_GRID_NT 768
+#endif
+// Threads per workgroup of the grid kernel.  Two workgroups share a CU's LDS, so the block size sets the occupancy:
+// 512 threads = 4 waves per SIMD (128 VGPRs), 768 = 6 waves (80 VGPRs).  With one ray per lane the trace loop fits
+// the smaller budget, and the two extra waves fill the issue slots the lockstep walk and the record gathers leave
+// idle: 2.16 -> 1.95 ms (640 threads: 10 waves do not spread evenly over 4 SIMDs, 2.9 ms; 1024: 64 VGPRs spill, 3.3 ms).
+constexpr int kGridNT = NLOS_GRID_NT;
+constexpr int kGridWaves = kGridNT / 64;
 
 __device__ __forceinline__ uint32_t make_entry(const GridView& g, const BBoxF& bb, int xx, int yy, uint32_t zq, int k) {
     // the box is widened by 0.02 sub-cells: > 50x the fp32 error of the two projections (rcp, 1 ulp)
@@ -285,7 +295,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     uint32_t* s_zc = s_union;                                                   // build phase
     unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(s_zc + ((R2 * R2 + 1) & ~1));
     uint32_t* s_queue = s_union;                                                // trace phase
-    const int union_words = max(((R2 * R2 + 1) & ~1) + 2 * mask_blocks, 8 * kQueueWords);
+    const int union_words = max(((R2 * R2 + 1) & ~1) + 2 * mask_blocks, kGridWaves * kQueueWords);
     uint32_t* s_ent = s_union + ((union_words + 1) & ~1);
     // build phase only: list length per cell (clamped to 255) in the part of the union the masks leave free,
     // so that the fill pass can bucket the live faces while it has their projection at hand
@@ -976,9 +986,9 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
 // PASS >= 0 fixes the pass at compile time (the single-workgroup grid: the usually idle big-LDS launch then
 // shows up under its own kernel name in profiles); PASS = -1 takes it from the argument.
 template <int FEAT, int NCM = 0, bool TILED = false, int PASS = -1>
-__global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows_in_lds, int R, int cap, int pass_arg = 0,
+__global__ __launch_bounds__(kGridNT, kGridNT / 128) void k_forward_grid(ForwardArgs a, int rows_in_lds, int R, int cap, int pass_arg = 0,
                                                          int last_pass = 1) {
-    __shared__ uint32_t s_scan[512];
+    __shared__ uint32_t s_scan[kGridNT];
     __shared__ uint32_t s_bkt[32];                   // live faces per list-length bucket, then the write cursors
     const int pass = PASS >= 0 ? PASS : pass_arg;
     if (pass >= 1 && a.retry[blockIdx.x] != pass) return;  // second launch: only the workgroups flagged for it
@@ -990,7 +1000,7 @@ __global__ __launch_bounds__(512, 4) void k_forward_grid(ForwardArgs a, int rows
 
 // LDS budget of the grid kernel: two 512-thread workgroups per CU -- 160 KiB / 2, minus the kernel's static
 // arrays (s_scan 2 KiB, s_bkt 128 B); one byte more and only one workgroup fits a CU (2.4 -> 3.9 ms)
-constexpr size_t kGridLdsBudget = 78 * 1024 - 128;
+constexpr size_t kGridLdsBudget = 78 * 1024 - 128 - (kGridNT - 512) * 4;
 
 template <int FEAT, int NCM = 0>
 bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
@@ -1007,7 +1017,7 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
     const size_t nblk = ((size_t)a.sc.F + 63) / 64;
     const size_t R2 = ((size_t)R + 1) / 2;
     size_t union_words = ((R2 * R2 + 1) & ~(size_t)1) + 2 * nblk;
-    if (union_words < 8 * kQueueWords) union_words = 8 * kQueueWords;
+    if (union_words < (size_t)kGridWaves * kQueueWords) union_words = (size_t)kGridWaves * kQueueWords;
     const size_t fixed = 32 + (rows_in_lds ? (size_t)a.sp.nbins * sizeof(double) : 0) + (((size_t)R * R + 2) & ~(size_t)1) * 4 +
                          ((union_words + 1) & ~(size_t)1) * 4;
     if (fixed + 4 * 2 * (size_t)a.sc.F > kGridLdsBudget || !a.live || !a.cov) { note.reason = 3; return false; }   // want room for >= 2 entries per face
@@ -1024,10 +1034,10 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
     note.retry_workgroups = a.retry ? a.src.L : 0;
     // kScan slots of slack: the walk reads kScan entries per trip and may touch the slots after the last list
     const int last_pass = a.retry ? 1 : 0;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, false, 0>), dim3(a.src.L), dim3(512), lds, stream, a, rows_in_lds, R,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, false, 0>), dim3(a.src.L), dim3(kGridNT), lds, stream, a, rows_in_lds, R,
                        (int)cap - kScan, 0, last_pass);
     if (a.retry)      // sources whose cell lists overflowed even on the coarsened grid: once more with the whole CU's LDS
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, false, 1>), dim3(a.src.L), dim3(512), lds_big, stream, a,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, false, 1>), dim3(a.src.L), dim3(kGridNT), lds_big, stream, a,
                            rows_in_lds, R, (int)((lds_big - fixed) / 4) - kScan, 1, last_pass);
     return true;
 }
@@ -1049,7 +1059,7 @@ bool forward_tiled_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t str
     const size_t R2 = (R + 1) / 2;
     const size_t mask_blocks = ((size_t)a.tile_cap + 63) / 64;
     size_t union_words = ((R2 * R2 + 1) & ~(size_t)1) + 2 * mask_blocks;
-    if (union_words < 8 * kQueueWords) union_words = 8 * kQueueWords;
+    if (union_words < (size_t)kGridWaves * kQueueWords) union_words = (size_t)kGridWaves * kQueueWords;
     const size_t fixed = 32 + (rows_in_lds ? (size_t)a.sp.nbins * sizeof(double) : 0) + (((size_t)R * R + 2) & ~(size_t)1) * 4 +
                          ((union_words + 1) & ~(size_t)1) * 4;
     if (fixed + 4 * 4096 > kGridLdsBudget) { note.reason = 4; return false; }
@@ -1068,9 +1078,9 @@ bool forward_tiled_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t str
     const size_t cap_big = (lds_big - fixed) / 4;
     note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big), "hipFuncSetAttribute(k_forward_grid tiled)");
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, true>), dim3((unsigned)nwg), dim3(512), lds, stream, a, rows_in_lds, R,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, true>), dim3((unsigned)nwg), dim3(kGridNT), lds, stream, a, rows_in_lds, R,
                        (int)cap - kScan, 0, 1);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, true>), dim3((unsigned)nwg), dim3(512), lds_big, stream, a, rows_in_lds,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, true>), dim3((unsigned)nwg), dim3(kGridNT), lds_big, stream, a, rows_in_lds,
                        R, (int)cap_big - kScan, 1, 1);
     return true;
 }

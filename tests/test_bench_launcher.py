@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 
 STANDIN = os.path.join(ROOT, "tests", "_bench_standin.py")
-SMALL = ["--grid", "4", "--num-sample", "5000", "--steps", "1", "--warmup", "0", "--sustain-seconds", "0"]
+SMALL = ["--grid", "4", "--num-sample", "5000", "--steps", "1", "--warmup", "0", "--sustain-seconds", "0", "--prewarm-seconds", "0"]
 
 
 def _run(cmd, env=None, timeout=600):
