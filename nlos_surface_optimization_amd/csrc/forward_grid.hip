@@ -56,6 +56,7 @@ __device__ __forceinline__ void load_face_tri(const SceneView& sc, int j, Face& 
     f.i2 = (FEAT & (FEAT_VN | FEAT_ALB)) ? __float_as_int(sc.facerec[4 * j + 3].x) : 0;
     tr.p0 = f.p0; tr.e1 = f.p0 - f.p1; tr.e2 = f.p2 - f.p0;
     tr.ng = mk(tc.y, tc.z, tc.w);
+    tr.gmin = kGrazeRatio * td.z;
     f.area = td.z;
     f.degenerate = !(f.area > 0.0f);
     f.fn = tr.ng * td.w;
@@ -139,7 +140,9 @@ template <class Fn, class Pre = RasterAll>
 __device__ __forceinline__ void raster_cells(float gx0, float gy0, float inv_cw, float inv_ch, int Rx, const Proj2& q, Fn fn,
                                              Pre pre = Pre()) {
     const float cw = __builtin_amdgcn_rcpf(inv_cw), ch = __builtin_amdgcn_rcpf(inv_ch);
-    const float mgx = 1e-3f * cw, mgy = 1e-3f * ch;          // >> fp32 rounding of the projection
+    // slack: the projection's rounding (1e-7) and, above all, the error of a reported hit under the grazing rule
+    // (<= ~1e-5 of the source-to-triangle distance laterally, i.e. < 1e-3 of a cell at the resolutions used)
+    const float mgx = 2e-3f * cw, mgy = 2e-3f * ch;
     const int cx0 = cell_coord(fminf(fminf(q.ax, q.bx), q.cx) - mgx, gx0, inv_cw, Rx);
     const int cx1 = cell_coord(fmaxf(fmaxf(q.ax, q.bx), q.cx) + mgx, gx0, inv_cw, Rx);
     const int cy0 = cell_coord(fminf(fminf(q.ay, q.by), q.cy) - mgy, gy0, inv_ch, Rx);
@@ -152,9 +155,9 @@ __device__ __forceinline__ void raster_cells(float gx0, float gy0, float inv_cw,
     const float A0 = -(q.by - q.ay) * sgn, B0 = (q.bx - q.ax) * sgn, C0 = -(A0 * q.ax + B0 * q.ay);
     const float A1 = -(q.cy - q.by) * sgn, B1 = (q.cx - q.bx) * sgn, C1 = -(A1 * q.bx + B1 * q.by);
     const float A2 = -(q.ay - q.cy) * sgn, B2 = (q.ax - q.cx) * sgn, C2 = -(A2 * q.cx + B2 * q.cy);
-    const float t0 = 2e-3f * (fabsf(A0) * cw + fabsf(B0) * ch);
-    const float t1 = 2e-3f * (fabsf(A1) * cw + fabsf(B1) * ch);
-    const float t2 = 2e-3f * (fabsf(A2) * cw + fabsf(B2) * ch);
+    const float t0 = 4e-3f * (fabsf(A0) * cw + fabsf(B0) * ch);
+    const float t1 = 4e-3f * (fabsf(A1) * cw + fabsf(B1) * ch);
+    const float t2 = 4e-3f * (fabsf(A2) * cw + fabsf(B2) * ch);
     // value at the first cell's inside-most corner (+ slack), and the steps per cell
     const float x00 = gx0 + (float)cx0 * cw, y00 = gy0 + (float)cy0 * ch;
     float E0 = A0 * (x00 + (A0 > 0 ? cw : 0.0f)) + B0 * (y00 + (B0 > 0 ? ch : 0.0f)) + (C0 + t0);
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(512) void k_tile_bin(ForwardArgs a, int R, int from
     const int ntx = a.tiles_x, nty = a.tiles_y;
     const float tw = fr.wx * 1.002f / (float)ntx, th = fr.wy * 1.002f / (float)nty;
     const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
-    const float mx = 2e-3f * tw / (float)R, my = 2e-3f * th / (float)R;
+    const float mx = 4e-3f * tw / (float)R, my = 4e-3f * th / (float)R;
     // slot allocation with LDS counters (one workgroup owns the whole source): global atomics on the few
     // per-tile counters were the bottleneck (2.5 ms for 1024 sources x 20 k faces)
     __shared__ int s_cnt[1024];
@@ -820,7 +823,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     rmask = (1u << (IB + sx)) | (1u << (IB + kSub + sy));
                     // depth level of the own-face hit, rounded up: anything quantised deeper cannot occlude
                     const float zs = t_self * dir.z;
-                    const uint32_t rq = (uint32_t)min(max((int)floorf((zs * 1.00002f - g.z0) * g.inv_qz) + 1, 0), g.zmax);
+                    const uint32_t rq = (uint32_t)min(max((int)floorf((zs * 1.0001f - g.z0) * g.inv_qz) + 1, 0), g.zmax);
                     rlim = (rq << (IB + 2 * kSub)) | ((1u << (IB + 2 * kSub)) - 1u);
                     const int c = cyy * R + cxx;
                     e1 = s_cell[c];
@@ -851,8 +854,8 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                         const int ofid = __shfl(fid, owner);
                         if (qi < n) {
                             const int kg = gid(k);
-                            const Tri tk = load_tri(a.sc.tris, kg);
-                            if (tri_occludes(tk, o, od, ot, ofid, a.sc.face_id, kg))
+                            const Tri tk = load_tri48(a.sc.tris, kg);
+                            if (tri_occludes(tk, o, od, ot, ofid, a.sc.face_id, kg, a.sc.tris))
                                 atomicOr(&wocc[owner >> 5], 1u << (owner & 31));
                         }
                     }

@@ -54,8 +54,15 @@ __device__ __forceinline__ void sample_st(uint64_t seed, uint64_t k, float& S, f
 // ------------------------------------------------------------ triangle record
 // 64-byte record (one cache-line half, 4 x dwordx4), sorted (Morton) order:
 //   p0, e1 = p0-p1, e2 = p2-p0, ng = e2 x e1, zmin (smallest vertex z), original face id
-struct Tri { V3 p0, e1, e2, ng; };
-constexpr int kTriStride = 4;   // float4 per record
+// Grazing rule (numeric contract): a ray that meets a
+// triangle's plane at less than asin(2^-6) = 0.9 degrees does not hit it: |ng . d| >= gmin = |ng| / 64 =
+// kGrazeRatio * area is part of the hit test, for the sampled face and for occluders alike.  Below that angle
+// t = T / den is only as good as den and the reported hit can lie millimetres off the ray, where no culled query
+// can follow it; above it every back-end (perspective grid, tiled grid, BVH packets, stackless BVH) enumerates
+// exactly the hits of the all-faces definition.
+constexpr float kGrazeRatio = 0.03125f;
+struct Tri { V3 p0, e1, e2, ng; float gmin; };
+constexpr int kTriStride = 4;   // float4 per record: p0, e1, e2, ng | zmin, face id, area, 1 / (2 area)
 
 __device__ __forceinline__ Tri make_tri(V3 p0, V3 p1, V3 p2) {
     Tri t;
@@ -63,6 +70,7 @@ __device__ __forceinline__ Tri make_tri(V3 p0, V3 p1, V3 p2) {
     t.e1 = p0 - p1;
     t.e2 = p2 - p0;
     t.ng = cross(t.e2, t.e1);
+    t.gmin = kGrazeRatio * (sqrtf(dot(t.ng, t.ng)) / 2.0f);
     return t;
 }
 
@@ -73,6 +81,19 @@ __device__ __forceinline__ Tri load_tri(const float4* __restrict__ tris, int j) 
     t.e1 = mk(a.w, b.x, b.y);
     t.e2 = mk(b.z, b.w, c.x);
     t.ng = mk(c.y, c.z, c.w);
+    t.gmin = kGrazeRatio * tris[kTriStride * j + 3].z;          // area, evaluated by the scene build
+    return t;
+}
+
+// the 48-byte part only (candidate loops: the grazing bound is fetched by the rare lanes that have a valid hit)
+__device__ __forceinline__ Tri load_tri48(const float4* __restrict__ tris, int j) {
+    float4 a = tris[kTriStride * j], b = tris[kTriStride * j + 1], c = tris[kTriStride * j + 2];
+    Tri t;
+    t.p0 = mk(a.x, a.y, a.z);
+    t.e1 = mk(a.w, b.x, b.y);
+    t.e2 = mk(b.z, b.w, c.x);
+    t.ng = mk(c.y, c.z, c.w);
+    t.gmin = 0.0f;
     return t;
 }
 
@@ -92,6 +113,7 @@ __device__ __forceinline__ bool tri_test(const Tri& tr, V3 o, V3 d, float& t, fl
     if (!ok) return false;
     float Tn = flipsign(dot(tr.ng, c), sg);
     if (!(0.0f < Tn)) return false;
+    if (!(aden >= tr.gmin)) return false;          // grazing rule
     float rcp = 1.0f / aden;
     u = U * rcp;
     v = Vv * rcp;
@@ -111,14 +133,16 @@ __device__ __forceinline__ bool tri_hit_t(const Tri& tr, V3 o, V3 d, float& t) {
     float Vv = flipsign(dot(r, tr.e1), sg);
     float Tn = flipsign(dot(tr.ng, c), sg);
     t = Tn * (1.0f / aden);
-    return (den != 0.0f) & (U >= 0.0f) & (Vv >= 0.0f) & (U + Vv <= aden) & (0.0f < Tn);
+    return (den != 0.0f) & (U >= 0.0f) & (Vv >= 0.0f) & (U + Vv <= aden) & (0.0f < Tn) & (aden >= tr.gmin);
 }
 
 // Occluder test against the own-face hit at distance t_self (original face id self_fid):
 // does triangle `tr` (original id via face_id[k]) give a valid hit that wins the closest-hit rule?
 // Same arithmetic as tri_test(); the division is only reached by lanes with a valid hit (rare).
+// `tr` may come from load_tri48(): the grazing bound of triangle k is read from `tris` by the lanes that need it.
 __device__ __forceinline__ bool tri_occludes(const Tri& tr, V3 o, V3 d, float t_self, int self_fid,
-                                             const int* __restrict__ face_id, int k) {
+                                             const int* __restrict__ face_id, int k,
+                                             const float4* __restrict__ tris) {
     V3 c = tr.p0 - o;
     V3 r = cross(c, d);
     float den = dot(tr.ng, d);
@@ -130,9 +154,10 @@ __device__ __forceinline__ bool tri_occludes(const Tri& tr, V3 o, V3 d, float t_
     bool valid = (den != 0.0f) & (U >= 0.0f) & (Vv >= 0.0f) & (U + Vv <= aden) & (0.0f < Tn);
     bool occ = false;
     if (valid) {
+        const float gmin = kGrazeRatio * reinterpret_cast<const float*>(tris)[4 * (kTriStride * k + 3) + 2];
         float t = Tn * (1.0f / aden);
-        occ = t < t_self;
-        if (t == t_self) occ = face_id[k] < self_fid;
+        occ = (aden >= gmin) && t < t_self;
+        if (aden >= gmin && t == t_self) occ = face_id[k] < self_fid;
     }
     return occ;
 }

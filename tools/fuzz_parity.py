@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Randomised parity sweep: GPU (all occlusion back-ends) vs the CPU oracle on random meshes, sources,
 windows and sample counts.  The accept/reject decisions must be identical, so the forward rows agree
-to fp64 summation order (~1e-15).  The sweep reports every case above 1e-12 and fails above 1e-5 (more than
-a grazing-occluder sample or two); gradient 1e-4.  Usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+to fp64 summation order (~1e-15).  The sweep FAILS on any case above 1e-12, i.e. on a single differing sample
+(with the grazing rule of DESIGN.md section 2 every back-end enumerates exactly the hits of the all-faces
+definition); gradient 1e-4.  On meshes of up to 3000 faces the oracle's own BVH mode is also checked against
+its brute-force mode (the definition).  Usage: python tools/fuzz_parity.py [n_cases] [seed]"""
 import os
 import sys
 
@@ -99,6 +101,11 @@ def main():
             vn = vertex_normals(v, f)
         kw = dict(accel=1, seed=case, vnormal=vn)
         t_ref, _ = orc.render_transient(o, nrm, v, f, ns, lb, ub, res, **kw)
+        e_def = 0.0
+        if F <= 3000:
+            # the definition: closest hit over ALL faces (no acceleration structure)
+            t_def, _ = orc.render_transient(o, nrm, v, f, ns, lb, ub, res, accel=0, seed=case, vnormal=vn)
+            e_def = rel_l2(t_ref, t_def)
         r = nd.TransientRenderer(dev, seed=case)
         tv, tf_, to, tn = (torch.from_numpy(x).to(dev) for x in (v, f, o, nrm))
         tvn = None if vn is None else torch.from_numpy(vn).to(dev)
@@ -106,7 +113,7 @@ def main():
         for fb in (0, 1) + ((2,) if F > 6200 else ()):
             t, _ = r.render_transient(to, tn, tv, tf_, ns, lb, ub, res, vertex_normal=tvn, force_bvh=fb)
             errs.append(rel_l2(t.cpu().numpy(), t_ref))
-        et = max(errs)
+        et = max(errs + [e_def])
         eg = 0.0
         if t_ref.sum() > 0 and rs.rand() < 0.6:
             data = t_ref * (1 + 0.3 * rs.standard_normal(t_ref.shape))
@@ -160,15 +167,15 @@ def main():
             ex = max(ex, rel_l2(it.cpu().numpy(), it_ref) if it_ref.sum() > 0 else 0.0)
             et = max(et, ex)
         r.close()
-        ok = et <= 1e-5 and eg <= 1e-4          # 1e-5: a grazing-occluder sample or two
+        ok = et <= 1e-12 and eg <= 1e-4         # 1e-12: fp64 summation order only -- a single differing sample fails
         grazing += int(et > 1e-12)
         if not ok and t_ref.sum() > 0:
             bad += 1
         worst_t, worst_g = max(worst_t, et), max(worst_g, eg)
-        print("case %3d F=%6d L=%d spt=%2d T=%4d vn=%d sum=%.3e  transient %.2e (grid/bvh%s)  gradient %.2e  nc %.2e  ggx/jitter/intensity %.2e %s" % (
-            case, F, L, spt, T, int(use_vn), t_ref.sum(), et, "/ovf" if F > 6200 else "", eg, en, ex, "" if ok else "  <-- MISMATCH"),
+        print("case %3d F=%6d L=%d spt=%2d T=%4d vn=%d sum=%.3e  transient %.2e (grid/bvh%s, oracle bvh vs all-faces %.1e)  gradient %.2e  nc %.2e  ggx/jitter/intensity %.2e %s" % (
+            case, F, L, spt, T, int(use_vn), t_ref.sum(), et, "/ovf" if F > 6200 else "", e_def, eg, en, ex, "" if ok else "  <-- MISMATCH"),
             flush=True)
-    print("cases with a differing sample (grazing-occluder candidates, see tools/fuzz_case.py): %d" % grazing)
+    print("cases with a differing sample (see tools/fuzz_case.py): %d" % grazing)
     print("worst transient %.3e, worst gradient %.3e, mismatches %d / %d" % (worst_t, worst_g, bad, n_cases))
     return 1 if bad else 0
 
