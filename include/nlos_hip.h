@@ -117,6 +117,16 @@ int nlos_v1_streamed_render_transient(float *origin, int numSources, float *norm
         int *triangles, int numTriangles, int numSamples, float lowerBound,
         float upperBound, float resolution, double *transient, double *pathlengths);
 
+/* stratified_transient_raytracer/stratifiedTransientRenderer.h (v1, NOT streamed: one wall point, rows are
+ * 1-D; renderer.pyx:93-102 `renderTransient`, still called by stratified_transient_raytracer/test.py:37).
+ * Same estimator as the v1 streamed forward for numSources = 1 (unclamped form factor, face normals, no
+ * albedo).  The reference body (stratifiedTransientRenderer.cpp:26-130) bins with the length of the SAMPLED
+ * point and normalises the direction by a division; this entry uses the streamed kernel's hit-point length and
+ * reciprocal multiply: identical but for a sample whose half path length sits within 1 ulp of a bin edge. */
+int nlos_v1_render_transient(float *origin, float *normal, float *vertices, int numVertices,
+        int *triangles, int numTriangles, int numSamples, float lowerBound, float upperBound,
+        float resolution, double *transient, double *pathlengths);
+
 /* Non-confocal (laser, sensor) pairs -- SURVEY.md 8a row N.  No native reference function exists
  * (prototypes: transient_rendering_python/rendering.py:8-93, mesh_optimization/rendering.py:739-797);
  * the parameter lists extend streamed_render_transient / streamed_render_gradient by the sensor

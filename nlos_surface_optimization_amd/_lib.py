@@ -125,6 +125,7 @@ SYMBOLS = {
     "nlos_ggx_streamed_render_gradient_alpha": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _F, _I, _F, _F, _F, _P, _P, _I, _I, _P]),
     "nlos_v1_streamed_render_gradient": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _I, _P, _P, _P]),
     "nlos_v1_streamed_render_transient": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P]),
+    "nlos_v1_render_transient": (_I, [_P, _P, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P]),
     "nlos_streamed_render_normal_smoothing": (_I, [_P, _I, _P, _I, _P, _P, _P]),
     "nlos_streamed_render_curvature_grad": (_I, [_P, _I, _P, _I, _P]),
     "nlos_set_regulariser_overwrite": (None, [_I]),

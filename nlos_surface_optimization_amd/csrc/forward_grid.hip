@@ -105,7 +105,7 @@ constexpr int kRound = NLOS_EXACT_ROUND;   // pairs per exact-test round: one pe
 #endif
 constexpr int kScan = NLOS_SCAN_WIDTH;      // cell-list entries per trip of the lockstep walk
 constexpr int kQueueCap = kRound + 64;      // a trip appends at most 64 pairs per slot before the drain check
-constexpr int kQueueWords = kQueueCap + 2;  // + the wave's 64-bit occlusion mask
+constexpr int kQueueWords = kQueueCap + 3;  // + a dump slot for the lanes that append nothing + the wave's 64-bit occlusion mask
 #ifndef NLOS_GRID_NT
 #define NLOS_GRID_NT 768
 #endif
@@ -173,6 +173,13 @@ __device__ __forceinline__ void raster_cells(float gx0, float gy0, float inv_cw,
         }
         E0 += by0; E1 += by1; E2 += by2;
     }
+}
+// first cell of the bounding box as raster_cells() derives it (same expressions, same bits)
+__device__ __forceinline__ void raster_origin(const GridView& g, const Proj2& q, int& cx0, int& cy0) {
+    const float cw = __builtin_amdgcn_rcpf(g.inv_cw), ch = __builtin_amdgcn_rcpf(g.inv_ch);
+    const float mgx = 2e-3f * cw, mgy = 2e-3f * ch;
+    cx0 = cell_coord(fminf(fminf(q.ax, q.bx), q.cx) - mgx, g.gx0, g.inv_cw, g.R);
+    cy0 = cell_coord(fminf(fminf(q.ay, q.by), q.cy) - mgy, g.gy0, g.inv_ch, g.R);
 }
 template <class Fn, class Pre = RasterAll>
 __device__ __forceinline__ void raster_tri(const GridView& g, const Proj2& q, Fn fn, Pre pre = Pre()) {
@@ -305,7 +312,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     uint8_t* s_len8 = reinterpret_cast<uint8_t*>(s_mask + mask_blocks);
     const bool len_ok = (((R2 * R2 + 1) & ~1) + 2 * mask_blocks) * 4 + ncell <= union_words * 4;
     uint16_t* g_live = a.live + (size_t)blockIdx.x * (TILED ? a.tile_cap : F);
-    uint32_t* g_cov = a.cov + (size_t)blockIdx.x * (TILED ? a.tile_cap : F);     // per-triangle cell coverage, count -> fill pass
+    uint16_t* g_cov = a.cov + (size_t)blockIdx.x * (TILED ? a.tile_cap : F);     // per-triangle cell coverage, count -> fill pass
     uint32_t* tl = TILED ? a.tile_list + (size_t)blockIdx.x * a.tile_cap : nullptr;
 
     const int l = TILED ? (int)(blockIdx.x / (unsigned)ntiles) : (int)blockIdx.x;
@@ -512,8 +519,10 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
                 const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
                 const uint32_t zn = __float_as_uint(fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f));
-                // the cells the triangle enters are remembered for the fill pass (one word per triangle in global
-                // scratch): bounding boxes of up to 4 x 4 cells as a bit mask, larger ones are rasterised again
+                // the cells the triangle enters are remembered for the fill pass (16 bits per triangle in global
+                // scratch): a bit per cell of a bounding box of up to 4 x 4 cells, relative to its first cell (which
+                // the fill pass re-derives from the projection); 0xFFFF = rasterise again (larger boxes, and the
+                // rare box that is entered in all sixteen cells)
                 int bx0 = 0, by0 = 0;
                 bool big = false, reach = false;
                 uint32_t cv = 0u;
@@ -528,7 +537,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     reach = reachable(zn)(cx0, cx1, cy0, cy1);
                     return reach;
                 });
-                g_cov[jl] = !reach ? 0u : big ? 0x80000000u : (((uint32_t)bx0 << 24) | ((uint32_t)by0 << 17) | cv);
+                g_cov[jl] = (uint16_t)(!reach ? 0u : big ? 0xFFFFu : cv);
             }
         }
         __syncthreads();
@@ -586,9 +595,9 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             // object), a mask of up to 4 x 4 cells, or a large bounding box that is rasterised again
             const uint32_t cov = g_cov[jl];
             const bool counts_as_live = fill_buckets && ((s_mask[jl >> 6] >> (jl & 63)) & 1ull);
-            if ((cov & 0x8000FFFFu) == 0u && !counts_as_live) continue;
+            if (cov == 0u && !counts_as_live) continue;
             uint32_t nmax = 0u;                              // longest list among the cells the triangle enters
-            if (cov & 0x8000FFFFu) {
+            if (cov) {
                 const int j = gid(jl);
                 const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
                 const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
@@ -598,7 +607,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 BBoxF bb;
                 bb.x0 = fminf(fminf(q.ax, q.bx), q.cx); bb.x1 = fmaxf(fmaxf(q.ax, q.bx), q.cx);
                 bb.y0 = fminf(fminf(q.ay, q.by), q.cy); bb.y1 = fmaxf(fmaxf(q.ay, q.by), q.cy);
-                if (cov & 0x80000000u) {
+                if (cov == 0xFFFFu) {
                     raster_tri(g, q, [&](int xx, int yy) {
                         if (zn <= s_zc[(yy >> 1) * R2 + (xx >> 1)]) {
                             const int c = yy * R + xx;
@@ -608,8 +617,9 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                         }
                     }, reachable(zn));
                 } else {
-                    const int bx0 = (int)((cov >> 24) & 127u), by0 = (int)((cov >> 17) & 127u);
-                    for (uint32_t m = cov & 0xFFFFu; m; m &= m - 1u) {
+                    int bx0, by0;
+                    raster_origin(g, q, bx0, by0);
+                    for (uint32_t m = cov; m; m &= m - 1u) {
                         const int bit = __ffs((int)m) - 1;
                         const int xx = bx0 + (bit & 3), yy = by0 + (bit >> 2);
                         const int c = yy * R + xx;
@@ -718,8 +728,8 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
 #define TMARK() do { } while (0)
 #define TACC(v) do { } while (0)
 #endif
-    uint32_t* wq = s_queue + wave * kQueueCap;           // this wave's pair queue (aliases the build-phase tables)
-    uint32_t* wocc = s_queue + nwaves * kQueueCap + wave * 2;  // this wave's 64-bit occlusion mask
+    uint32_t* wq = s_queue + wave * (kQueueCap + 1);     // this wave's pair queue (aliases the build-phase tables) + dump slot
+    uint32_t* wocc = s_queue + nwaves * (kQueueCap + 1) + wave * 2;  // this wave's 64-bit occlusion mask
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     // GRID (workgroup-uniform): occlusion through the cell lists; otherwise (scene not strictly in front of the
@@ -872,7 +882,9 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 auto push = [&](bool pass, uint32_t w) {
                     const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
                     if (m) {
-                        if (pass) wq[qn + __popcll(m & lt_mask)] = ((uint32_t)lane << 16) | (w & imask);
+                        // every lane stores (the ones that append nothing into the dump slot): a select instead of a
+                        // divergent region, so the compare mask feeds the ballot and the select directly
+                        wq[pass ? qn + __popcll(m & lt_mask) : kQueueCap] = ((uint32_t)lane << 16) | (w & imask);
                         qn += __popcll(m);
                         if (qn >= kRound) {
                             TACC(ts);

@@ -530,17 +530,17 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     int chunk_L = L > 0 ? L : 1;                       // sources per pass-1 launch
     if (nF <= tile_threshold && a->force_bvh != 1) {
         rc = c->live.ensure(sizeof(uint16_t) * (size_t)(L > 0 ? L : 1) * nF + 16);
-        if (!rc) rc = c->cov.ensure(sizeof(uint32_t) * (size_t)(L > 0 ? L : 1) * nF + 16);
+        if (!rc) rc = c->cov.ensure(sizeof(uint16_t) * (size_t)(L > 0 ? L : 1) * nF + 16);
         if (!rc) rc = c->tile_count.ensure(sizeof(int) * (size_t)(L > 0 ? L : 1) + 16);
         if (rc) return rc;
         fa.live = c->live.as<uint16_t>();
-        fa.cov = c->cov.as<uint32_t>();
+        fa.cov = c->cov.as<uint16_t>();
         fa.retry = c->tile_count.as<int>();
     } else if (a->force_bvh != 1 && L > 0) {
         // tiled grid: ~3000 triangles per slope-space tile on average (small tiles leave the 512 threads idle); the densest tiles of a closed surface
         // (front + back side, several depth layers) hold up to ~4.5x the mean, and the subset capacity is bounded by
         // the 14-bit entry index (overflowing tiles fall back to the BVH query by themselves);
-        // scratch = 10 B per (source, tile, slot)
+        // scratch = 8 B per (source, tile, slot)
         static const int tile_tris = [] { const char* e = std::getenv("NLOS_TILE_TRIS"); return e && std::atoi(e) > 0 ? std::atoi(e) : 3000; }();
         const int nt = (nF + tile_tris - 1) / tile_tris;
         int side = 1;
@@ -549,7 +549,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         long long tcap = 6LL * nF / tiles + 512;
         if (tcap > 16383) tcap = 16383;
         if (a->force_bvh == 2) tcap = 64;              // diagnostic: force the subset-overflow fallback of the tiles
-        // the per-(source, tile) subsets are the largest scratch of the path (10 B per slot): bounded to 32 GB by
+        // the per-(source, tile) subsets are the largest scratch of the path (8 B per slot): bounded to 32 GB by
         // rendering the sources in chunks (NLOS_TILE_SCRATCH_MAX overrides the bound; nlos_ctx_last_path reports
         // the number of chunks)
         static const unsigned long long scratch_max = [] {
@@ -558,19 +558,19 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
             return v > 0 ? v : (32ull << 30);
         }();
         const unsigned long long per_source = (unsigned long long)tiles * (unsigned long long)tcap;
-        unsigned long long max_l = scratch_max / (10ull * per_source);
+        unsigned long long max_l = scratch_max / (8ull * per_source);
         if (max_l < 1) max_l = 1;
         if ((unsigned long long)L > max_l) chunk_L = (int)max_l;
         const unsigned long long slots = (unsigned long long)chunk_L * per_source;
         rc = c->live.ensure(sizeof(uint16_t) * slots + 16);
-        if (!rc) rc = c->cov.ensure(sizeof(uint32_t) * slots + 16);
+        if (!rc) rc = c->cov.ensure(sizeof(uint16_t) * slots + 16);
         if (!rc) rc = c->tile_list.ensure(sizeof(uint32_t) * slots + 16);
         if (!rc) rc = c->tile_count.ensure(sizeof(int) * 2 * (size_t)chunk_L * tiles + 16);
         if (rc) return rc;
         fa.tile_count = c->tile_count.as<int>();
         fa.retry = fa.tile_count + (size_t)chunk_L * tiles;
         fa.live = c->live.as<uint16_t>();
-        fa.cov = c->cov.as<uint32_t>();
+        fa.cov = c->cov.as<uint16_t>();
         fa.tile_list = c->tile_list.as<uint32_t>();
         fa.tiles_x = fa.tiles_y = side;
         fa.tile_cap = (int)tcap;
@@ -1290,6 +1290,15 @@ int nlos_v1_streamed_render_transient(float* origin, int numSources, float* norm
     h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
     h.transient = transient; h.pathlengths = pathlengths;
     return host_render(h);
+}
+
+int nlos_v1_render_transient(float* origin, float* normal, float* vertices, int numVertices, int* triangles,
+                             int numTriangles, int numSamples, float lowerBound, float upperBound, float resolution,
+                             double* transient, double* pathlengths) {
+    // stratified_transient_raytracer/stratifiedTransientRenderer.cpp:132-218: one source, rows [numBins]
+    return nlos_v1_streamed_render_transient(origin, 1, normal, vertices, numVertices, nullptr, nullptr, triangles,
+                                             numTriangles, numSamples, lowerBound, upperBound, resolution, transient,
+                                             pathlengths);
 }
 
 static int host_intersect(float* origins, float* directions, int num_ray, float* vertices, int num_vertices,

@@ -88,7 +88,7 @@ struct ForwardArgs {
     int force_bvh;           // 1: never use the per-source perspective grid (tests / large meshes)
     long long* dbg;          // diagnostic builds only (NLOS_FWD_STAMPS); null in the product
     uint16_t* live;          // [L, F] scratch: per-source bucketed list of contributing faces (grid kernel)
-    uint32_t* cov;           // [L, F] scratch: cells every triangle enters (counting pass -> fill pass of the grid kernel)
+    uint16_t* cov;           // [L, F] scratch: cells every triangle enters (counting pass -> fill pass of the grid kernel)
     uint32_t* vis2;          // [L, vis_words, F] scratch: sensor-leg visibility of non-confocal pairs (grid path) or null
     // tiled grid (meshes beyond one workgroup's LDS): slope space is cut into tiles_x * tiles_y tiles, one
     // workgroup per (source, tile); tile_list holds each workgroup's triangle subset (tile_cap ids each)

@@ -14,6 +14,41 @@ from ._check import f32, f64, i32, ptr
 from .renderer import _check_grad, _check_tp, _common, _num_bins
 
 
+def renderStreamedCurvatureGradient(vertices, faces, gradient):
+    """stratified_transient_raytracer/renderer.pyx:13-18 -> streamed_render_curvature_grad
+    (stratifiedStreamedGradientRenderer.cpp:298-348): the gradient of the total surface area, the same body as
+    the v2 module's (per-vertex terms accumulated over the incident faces; see renderer.set_regulariser_overwrite)."""
+    f32(vertices, 2, "vertices"); i32(faces, 2, "faces"); f64(gradient, 2, "gradient")
+    assert vertices.shape[1] == 3, "vertices needs to be Vx3"
+    assert faces.shape[1] == 3, "faces needs to be Fx3"
+    assert gradient.shape[0] == vertices.shape[0], "gradient dimension should be Vx3"
+    assert gradient.shape[1] == 3, "gradient dimension should be Vx3"
+    rc = _lib.lib().nlos_streamed_render_curvature_grad(
+        ptr(vertices), vertices.shape[0], ptr(faces), faces.shape[0], ptr(gradient))
+    _lib.check(rc, "v1 streamed_render_curvature_grad")
+
+
+def renderTransient(origin, normal, vertices, faces, num_sample, lower_bound, upper_bound, resolution,
+                    transient, pathlengths):
+    """stratified_transient_raytracer/renderer.pyx:93-102 -> render_transient (stratifiedTransientRenderer.cpp:
+    132-218): ONE wall point (origin, normal are [3]), rows are [numBins]; v1 estimator (unclamped form factor)."""
+    f32(origin, 1, "origin"); f32(normal, 1, "normal"); f32(vertices, 2, "vertices"); i32(faces, 2, "faces")
+    f64(transient, 1, "transient"); f64(pathlengths, 1, "pathlengths")
+    assert origin.shape[0] == 3, "origin needs to be 1x3"
+    assert normal.shape[0] == 3, "normal needs to be 1x3"
+    assert vertices.shape[1] == 3, "vertices needs to be Vx3"
+    assert faces.shape[1] == 3, "faces needs to be Fx3"
+    numBins = _num_bins(lower_bound, upper_bound, resolution)
+    assert transient.shape[0] == numBins, \
+        "transient dimension should match number of bins = math.ceil((upper_bound-lower_bound)/resolution)"
+    assert pathlengths.shape[0] == numBins, \
+        "pathlength dimension should match number of bins = math.ceil((upper_bound-lower_bound)/resolution)"
+    rc = _lib.lib().nlos_v1_render_transient(
+        ptr(origin), ptr(normal), ptr(vertices), vertices.shape[0], ptr(faces), faces.shape[0], int(num_sample),
+        lower_bound, upper_bound, resolution, ptr(transient), ptr(pathlengths))
+    _lib.check(rc, "v1 render_transient")
+
+
 def renderStreamedTransient(origin, normal, vertices, faces, num_sample, lower_bound, upper_bound,
                             resolution, transient, pathlengths):
     L = _common(origin, normal, vertices, faces)

@@ -175,6 +175,58 @@ def make_pyref_nc():
     np.savez_compressed(os.path.join(HERE, "pyref_angular_nc.npz"), **out)
 
 
+def make_pyref_grad():
+    """Central finite differences of the reference's numpy forward (rendering.py, imported) with respect to every
+    vertex coordinate, of the functional sum_b angular_transient[b] (what `backward(ones)` of the torch prototype
+    differentiates), on the test_autograd.py:35-36 toy mesh and the cfg-1 plane.  Face normals are recomputed
+    from the displaced vertices, as rendering_grad.py:100-107 does."""
+    sys.path.insert(0, os.path.join(REF, "transient_rendering_python"))
+    import rendering as pyref  # noqa: E402  (the reference module)
+
+    def forward(mv, mf, d, lighting, sensor, opt):
+        mesh = types.SimpleNamespace()
+        mesh.v, mesh.f = mv, mf
+        p1, p2, p3 = mv[mf[:, 0]], mv[mf[:, 1]], mv[mf[:, 2]]
+        fn = np.cross(p2 - p1, p3 - p1)
+        mesh.fn = fn / np.linalg.norm(fn, axis=1, keepdims=True)
+        return np.array(pyref.angular_sampling(mesh, d, lighting, sensor, np.array([0, 0, 1.0]), np.array([0, 0, 1.0]), opt))
+
+    out = {}
+    rs = np.random.RandomState(5)
+    v, f, _, _ = cfg1()
+    cases = {"plane": (v.astype(np.float64), f.astype(np.int64), 64),
+             "toy": (np.array([[-1, -1, .9], [1, -1, 1], [1, 1, 1.2], [-1, 1, 1], [-2, -2, 1], [2, 1, 1]], np.float64),
+                     np.array([[0, 2, 1], [0, 3, 2], [4, 3, 0], [1, 2, 5]], np.int64), 400)}
+    for name, (mv, mf, nbin) in cases.items():
+        n = 256
+        d = rs.normal(size=(n, 3))
+        d[:, 2] = np.abs(d[:, 2]) + 0.2
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        opt = types.SimpleNamespace(sample_num=n, max_distance_bin=nbin, distance_resolution=0.02, epsilon=1e-9, normal="fn")
+        pairs = [((0.1, 0, 0), (0.1, 0, 0)), ((-0.5, 0, 0), (0.5, 0, 0)) if name == "toy" else ((-0.1, 0, 0), (0.05, 0.1, 0))]
+        rows, grads = [], []
+        for lighting, sensor in pairs:
+            lighting, sensor = np.array(lighting, np.float64), np.array(sensor, np.float64)
+            rows.append(forward(mv, mf, d, lighting, sensor, opt))
+            g = np.zeros_like(mv)
+            h = 1e-6
+            for i in range(mv.shape[0]):
+                for k in range(3):
+                    vp, vm = mv.copy(), mv.copy()
+                    vp[i, k] += h
+                    vm[i, k] -= h
+                    g[i, k] = (forward(vp, mf, d, lighting, sensor, opt).sum() - forward(vm, mf, d, lighting, sensor, opt).sum()) / (2 * h)
+            grads.append(g)
+        out[name + "_v"], out[name + "_f"], out[name + "_dir"] = mv, mf, d
+        out[name + "_lighting"] = np.array([p[0] for p in pairs], np.float64)
+        out[name + "_sensor"] = np.array([p[1] for p in pairs], np.float64)
+        out[name + "_nbin"], out[name + "_res"] = np.int64(nbin), np.float64(0.02)
+        out[name + "_transient"] = np.stack(rows)
+        out[name + "_grad_fd"] = np.stack(grads)
+        print("pyref grad", name, np.stack(rows).sum(axis=1), np.abs(np.stack(grads)).max())
+    np.savez_compressed(os.path.join(HERE, "pyref_angular_grad.npz"), **out)
+
+
 def make_jitter_info():
     """The reference's measured SPAD jitter kernel (a data file its own jitter/test.py loads)."""
     import scipy.io
@@ -265,6 +317,7 @@ if __name__ == "__main__":
     bv, bf = make_meshes()
     make_pyref()
     make_pyref_nc()
+    make_pyref_grad()
     make_jitter_info()
     make_adam_modified()
     make_oracle_cfg1()

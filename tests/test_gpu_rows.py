@@ -140,6 +140,21 @@ def test_v1_rows_w_and_g1(mannequin, orc):
     renderer_v1.renderStreamedTransient(origin, normal, v, f, ns, lb, ub, res, tr, path)
     t_o, _ = orc.render_transient(origin, normal, v, f, ns, lb, ub, res, clamp=0, accel=1)
     assert rel_l2(tr, t_o) <= 1e-5
+    # v1 non-streamed renderTransient (stratified_transient_raytracer/renderer.pyx:93-102): ONE wall point, 1-D rows
+    row, path1 = np.zeros(Tn), np.zeros(Tn)
+    renderer_v1.renderTransient(np.ascontiguousarray(origin[4]), np.ascontiguousarray(normal[4]), v, f, ns, lb, ub, res, row, path1)
+    t_1, p_1 = orc.render_transient(origin[4:5], normal[4:5], v, f, ns, lb, ub, res, clamp=0, accel=1)
+    assert t_1.sum() > 0 and rel_l2(row, t_1[0]) <= 1e-5 and np.array_equal(path1, p_1)
+    with pytest.raises(AssertionError, match="origin needs to be 1x3"):
+        renderer_v1.renderTransient(np.zeros(2, np.float32), np.ascontiguousarray(normal[4]), v, f, ns, lb, ub, res, row, path1)
+    with pytest.raises(AssertionError, match="transient dimension should match number of bins"):
+        renderer_v1.renderTransient(np.ascontiguousarray(origin[4]), np.ascontiguousarray(normal[4]), v, f, ns, lb, ub, res,
+                                    np.zeros(Tn - 1), path1)
+    # v1 renderStreamedCurvatureGradient (renderer.pyx:13-18): the area gradient, same body as the v2 module's
+    g1 = np.full((v.shape[0], 3), 3.0)
+    renderer_v1.renderStreamedCurvatureGradient(v, f, g1)
+    _, g_ref = orc.mesh_regulariser(v, f)
+    assert np.abs(g_ref).max() > 0 and rel_l2(g1, g_ref) <= 1e-6
 
 
 def test_single_vertex_gradient(cfg1, orc):
