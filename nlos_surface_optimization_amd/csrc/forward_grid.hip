@@ -42,26 +42,6 @@ __device__ __forceinline__ int cell_coord(float m, float g0, float inv_c, int R)
     return min(max(c, 0), R - 1);
 }
 
-// Face + triangle of sorted slot j for the sample map.  Same values as load_face() / load_tri() (render_common.h,
-// nlos_device.h): e1, e2 are make_tri()'s own subtractions, ng == cross(p1 - p0, p2 - p0) bit for bit, and area,
-// 1 / (2 area) were evaluated by the scene build with load_face()'s expressions -- once per step instead of once
-// per (source, face).
-template <int FEAT>
-__device__ __forceinline__ void load_face_tri(const SceneView& sc, int j, Face& f, Tri& tr) {
-    const float4 fa = sc.facerec[4 * j], fb = sc.facerec[4 * j + 1], fc = sc.facerec[4 * j + 2];
-    const float4 tc = sc.tris[kTriStride * j + 2], td = sc.tris[kTriStride * j + 3];
-    f.p0 = mk(fa.x, fa.y, fa.z); f.p1 = mk(fa.w, fb.x, fb.y); f.p2 = mk(fb.z, fb.w, fc.x);
-    f.fid = __float_as_int(fc.y);
-    f.i0 = __float_as_int(fc.z); f.i1 = __float_as_int(fc.w);
-    f.i2 = (FEAT & (FEAT_VN | FEAT_ALB)) ? __float_as_int(sc.facerec[4 * j + 3].x) : 0;
-    tr.p0 = f.p0; tr.e1 = f.p0 - f.p1; tr.e2 = f.p2 - f.p0;
-    tr.ng = mk(tc.y, tc.z, tc.w);
-    tr.gmin = kGrazeRatio * td.z;
-    f.area = td.z;
-    f.degenerate = !(f.area > 0.0f);
-    f.fn = tr.ng * td.w;
-}
-
 struct Proj2 { float ax, ay, bx, by, cx, cy; };
 
 __device__ __forceinline__ Proj2 project_tri(V3 o, V3 p0, V3 p1, V3 p2) {
@@ -311,6 +291,10 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     // so that the fill pass can bucket the live faces while it has their projection at hand
     uint8_t* s_len8 = reinterpret_cast<uint8_t*>(s_mask + mask_blocks);
     const bool len_ok = (((R2 * R2 + 1) & ~1) + 2 * mask_blocks) * 4 + ncell <= union_words * 4;
+    // build-phase scratch of this workgroup: bucketed live list, per-triangle cell coverage.  (A pool of ~1500 regions
+    // handed from workgroup to workgroup instead of one region per source was tried, to keep the scratch in cache:
+    // the regions then migrate between the XCDs' L2s -- 1.75 GB of fabric traffic per launch instead of 0.49 GB and
+    // 2.29 ms instead of 1.91 ms.)
     uint16_t* g_live = a.live + (size_t)blockIdx.x * (TILED ? a.tile_cap : F);
     uint16_t* g_cov = a.cov + (size_t)blockIdx.x * (TILED ? a.tile_cap : F);     // per-triangle cell coverage, count -> fill pass
     uint32_t* tl = TILED ? a.tile_list + (size_t)blockIdx.x * a.tile_cap : nullptr;
@@ -455,9 +439,8 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             load_face_tri<FEAT>(a.sc, jg, f, tr_unused);
             const bool dark = face_dark(f);
             live = !dark;
-            if (!TILED && visout) {
-                // every word starts from zero: dark faces stay there, live faces receive their bits from the trace
-                // (stored whole, or OR-ed in pieces when a face's strata straddle two wave items)
+            if (!TILED && dark && visout) {
+                // dark faces: no sample is ever accepted (live faces receive their words from the trace)
                 uint32_t* visp = visout + ((size_t)l * a.vis_words) * F + j;
                 for (int wi = 0; wi < a.vis_words; ++wi) visp[(size_t)wi * F] = 0u;
             }
@@ -691,6 +674,17 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     __syncthreads();
     FWD_STAMP();   // 4: bucketed live list
     const int n_live = compact ? s_ctl[3] : Fl;
+    if (!TILED && visout) {
+        // The trace stores a visibility word whole when all its strata sit in one 64-ray item, and ORs the pieces of
+        // a word that straddles two items: those words -- at most one per item boundary -- start from zero.
+        const uint32_t n_r = (uint32_t)n_live * (uint32_t)a.sp.spt;
+        for (uint32_t rb = 64u * (uint32_t)(tid + 1); rb < n_r; rb += 64u * (uint32_t)NT) {
+            const uint32_t li = rb / (uint32_t)a.sp.spt;
+            const uint32_t sb = rb - li * (uint32_t)a.sp.spt;
+            if (sb & 31u) visout[((size_t)l * a.vis_words + (sb >> 5)) * F + gid(compact ? (int)g_live[li] : (int)li)] = 0u;
+        }
+        __syncthreads();
+    }
 
     // ---- trace + histogram: one RAY per lane ---------------------------------------------------------
     // The rays of a source are the (live face, stratum) pairs r = li * spt + s in the order of the bucketed

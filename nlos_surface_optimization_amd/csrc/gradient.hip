@@ -112,9 +112,10 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
             if (li >= n_live) continue;
             const int j = a.compact ? (int)s_live[li] : li;
             const uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
-            const Face f = load_face(a.sc.facerec, j);
+            Face f;
+            Tri tr;
+            load_face_tri<FEAT | FEAT_VN>(a.sc, j, f, tr);    // vertices, ids, and the per-face constants the scene build evaluated
             if (MODE == 3 && f.i0 != a.vertex_num && f.i1 != a.vertex_num && f.i2 != a.vertex_num) continue;
-            const Tri tr = make_tri(f.p0, f.p1, f.p2);      // what the builder stored (same function, same bits): no 48-B gather
             const uint64_t kbase = (lg * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
             double acc[9];
 #pragma unroll
@@ -344,8 +345,9 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
             const int bl = code >> 12, jl = code & 0xFFF;
             const int l = lb0 + bl, j = face_of(jl);
             const double* s_diff = s_rows + bl * T;
-            const Face f = load_face(a.sc.facerec, j);
-            const Tri tr = make_tri(f.p0, f.p1, f.p2);      // what the builder stored (same function, same bits): no 48-B gather
+            Face f;
+            Tri tr;
+            load_face_tri<FEAT | FEAT_VN>(a.sc, j, f, tr);    // vertices, ids, and the per-face constants the scene build evaluated
             const V3 o = ld3(a.src.origin + 3 * (size_t)l);
             const V3 on = ld3(a.src.normal + 3 * (size_t)l);
             const uint64_t kbase = ((uint64_t)(a.src.source_offset + l) * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;

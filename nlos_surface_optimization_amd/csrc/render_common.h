@@ -45,6 +45,26 @@ __device__ __forceinline__ Face load_face(const float4* __restrict__ rec, int j)
     return f;
 }
 
+// Face + triangle of sorted slot j for the sample map.  Same values as load_face() / load_tri() (render_common.h,
+// nlos_device.h): e1, e2 are make_tri()'s own subtractions, ng == cross(p1 - p0, p2 - p0) bit for bit, and area,
+// 1 / (2 area) were evaluated by the scene build with load_face()'s expressions -- once per step instead of once
+// per (source, face).
+template <int FEAT>
+__device__ __forceinline__ void load_face_tri(const SceneView& sc, int j, Face& f, Tri& tr) {
+    const float4 fa = sc.facerec[4 * j], fb = sc.facerec[4 * j + 1], fc = sc.facerec[4 * j + 2];
+    const float4 tc = sc.tris[kTriStride * j + 2], td = sc.tris[kTriStride * j + 3];
+    f.p0 = mk(fa.x, fa.y, fa.z); f.p1 = mk(fa.w, fb.x, fb.y); f.p2 = mk(fb.z, fb.w, fc.x);
+    f.fid = __float_as_int(fc.y);
+    f.i0 = __float_as_int(fc.z); f.i1 = __float_as_int(fc.w);
+    f.i2 = (FEAT & (FEAT_VN | FEAT_ALB)) ? __float_as_int(sc.facerec[4 * j + 3].x) : 0;
+    tr.p0 = f.p0; tr.e1 = f.p0 - f.p1; tr.e2 = f.p2 - f.p0;
+    tr.ng = mk(tc.y, tc.z, tc.w);
+    tr.gmin = kGrazeRatio * td.z;
+    f.area = td.z;
+    f.degenerate = !(f.area > 0.0f);
+    f.fn = tr.ng * td.w;
+}
+
 // per-sample geometry of an own-face hit
 struct Geo {
     float u, v, w, h;
