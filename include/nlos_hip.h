@@ -143,6 +143,21 @@ int nlos_nonconfocal_render_gradient(double *data, double *weight, float *laser,
         float resolution, double *transient, double *pathlengths, double *gradient,
         int refine_scale, int sigma_bin, int testing_flag, int loss_test);
 
+/* the same with the GGX BRDF of the `ggx` module (`float alpha` after numTriangles, as ggx/...Renderer.h place it):
+ * brdf = D(n.h) G1(n.w_laser) G1(n.w_sensor) / 4 with the half vector h -- ggx_confocal.cpp's eval() for
+ * w_laser == w_sensor */
+int nlos_ggx_nonconfocal_render_transient(float *laser, float *laserNormal, float *sensor,
+        float *sensorNormal, int numPairs, float *vertices, int numVertices,
+        float *vertexNormal, float *vertexAlbedo, int *triangles, int numTriangles, float alpha,
+        int numSamples, float lowerBound, float upperBound, float resolution,
+        double *transient, double *pathlengths, int refine_scale, int sigma_bin);
+int nlos_ggx_nonconfocal_render_gradient(double *data, double *weight, float *laser,
+        float *laserNormal, float *sensor, float *sensorNormal, int numPairs,
+        float *vertices, int numVertices, float *vertexNormal, float *vertexAlbedo,
+        int *triangles, int numTriangles, float alpha, int numSamples, float lowerBound, float upperBound,
+        float resolution, double *transient, double *pathlengths, double *gradient,
+        int refine_scale, int sigma_bin, int testing_flag, int loss_test);
+
 /* smoothed_transient/stratifiedStreamedGradientRenderer.h (streamed_render_normal_smoothing,
  * streamed_render_curvature_grad; bodies :27-180).  curvature_grad [numVertices,3] is zeroed and
  * filled; the reference returns the smoothing value, here it is written to *value_out.
@@ -266,7 +281,7 @@ typedef struct nlos_render_args {
      * surface point must be the closest hit seen from BOTH wall points, the path length is
      * d1 + d2, the form factor is the product of the two legs' clamped form factors; v2
      * conventions otherwise, so sensor == origin reproduces the confocal rows.  TRANSIENT and
-     * GRADIENT modes, Lambertian only. */
+     * GRADIENT modes; with use_ggx the BRDF is the half-vector form D(n.h) G1(n.wa) G1(n.wb) / 4. */
     const float *sensor;        /* [L,3] or NULL */
     const float *sensor_normal; /* [L,3] (required with sensor) */
     /* SPAD jitter variant (the reference's `jitter` module: jitter/transient_and_gradient.cpp:271-355,
@@ -311,7 +326,7 @@ enum {
     NLOS_REASON_TINY_MESH     = 2,  /* F < 64 */
     NLOS_REASON_LDS           = 3,  /* rows + cell tables leave no room for the cell lists */
     NLOS_REASON_TILE_LIMITS   = 4,  /* more than 1024 tiles, or the tile tables do not fit LDS */
-    NLOS_REASON_GGX_PAIRS     = 5,  /* non-confocal pairs with a feature the grid passes do not carry */
+    NLOS_REASON_GGX_PAIRS     = 5,  /* non-confocal pairs in a mode the grid passes do not carry (per-face intensity) */
     NLOS_REASON_LARGE_MESH    = 6   /* F beyond the single-workgroup grid: tiled */
 };
 typedef struct nlos_path_info {

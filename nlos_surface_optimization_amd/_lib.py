@@ -95,7 +95,7 @@ class PathInfo(ctypes.Structure):
 
 PATH_NAMES = {0: "none", 1: "grid", 2: "tiled-grid", 3: "bvh"}
 REASON_NAMES = {0: "", 1: "force_bvh", 2: "mesh below 64 faces", 3: "rows and cell tables leave no LDS for the cell lists",
-                4: "tile limits", 5: "non-confocal pairs with GGX", 6: "mesh beyond one workgroup's grid"}
+                4: "tile limits", 5: "non-confocal pairs in a mode the grid passes do not carry", 6: "mesh beyond one workgroup's grid"}
 GRADIENT_KERNEL_NAMES = {0: "none", 1: "source-major, LDS accumulator", 2: "source-major, global atomics", 3: "face-major"}
 
 
@@ -139,6 +139,8 @@ SYMBOLS = {
     "nlos_jitter_streamed_render_gradient": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F, _P, _P, _I, _I, _P, _P, _P, _I]),
     "nlos_nonconfocal_render_transient": (_I, [_P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _I, _I]),
     "nlos_nonconfocal_render_gradient": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _I, _I, _I, _I]),
+    "nlos_ggx_nonconfocal_render_transient": (_I, [_P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _F, _I, _F, _F, _F, _P, _P, _I, _I]),
+    "nlos_ggx_nonconfocal_render_gradient": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _F, _I, _F, _F, _F, _P, _P, _P, _I, _I, _I, _I]),
     "nlos_embree3_tbb_line_intersection": (_I, [_P, _P, _I, _P, _I, _P, _I, _P]),
     "nlos_embree3_tbb_short_line_intersection": (_I, [_P, _P, _I, _P, _I, _P, _I, _P]),
     "nlos_barycentric_to_world_n": (_I, [_P, _I, _P, _I, _P, _I, _P]),

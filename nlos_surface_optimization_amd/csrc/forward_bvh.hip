@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void k_forward_nc(ForwardArgs a, int rows_in_l
                     const float ffb = emax0(-dot(g.n, g.dirB) * dot(nb, g.dirB) / g.d2 / g.d2);
                     ok = ffa > 0.0f && ffb > 0.0f;      // zero contribution in both passes: never trace
                     vv = f.area * g.alb * ffa * ffb;
+                    if (FEAT & FEAT_GGX) vv = vv * ggx_pair<false>(a.sp.ggx_alpha, g.n, -g.dirA, -g.dirB).brdf;
                     bb = (int)floorf(((g.d1 + g.d2) - lb) / res);
                 }
                 ax[c] = ok ? g.dirA.x : 0.0f; ay[c] = ok ? g.dirA.y : 0.0f; az[c] = ok ? g.dirA.z : 1.0f;
@@ -312,8 +313,7 @@ __global__ __launch_bounds__(256) void k_forward_nc(ForwardArgs a, int rows_in_l
 template <int FEAT>
 void bvh_launch(const ForwardArgs& a, int rows_in_lds, size_t lds, hipStream_t stream) {
     if (a.src.sensor) {
-        if constexpr ((FEAT & FEAT_GGX) == 0)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_nc<FEAT, 4>), dim3(a.src.L), dim3(256), lds, stream, a, rows_in_lds);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_nc<FEAT, 4>), dim3(a.src.L), dim3(256), lds, stream, a, rows_in_lds);
         return;
     }
     // chunk = rays traced together per (source, face): 4 when spt <= 4, else 8

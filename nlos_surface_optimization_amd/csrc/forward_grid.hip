@@ -798,6 +798,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     const float ffb = emax0(-dot(gc.n, gc.dirB) * dot(onb, gc.dirB) / gc.d2 / gc.d2);
                     ok = ffa > 0.0f && ffb > 0.0f && ((word_b >> (s & 31)) & 1u);
                     val = f.area * gc.alb * ffa * ffb;
+                    if (FEAT & FEAT_GGX) val = val * ggx_pair<false>(a.sp.ggx_alpha, gc.n, -gc.dirA, -gc.dirB).brdf;
                     bin = (int)floorf(((gc.d1 + gc.d2) - lb) / res);
                     dir = gc.dirA;
                 }
@@ -1097,7 +1098,7 @@ bool forward_tiled_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t str
 template <int FEAT>
 bool grid_dispatch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
     if (a.src.sensor) {
-        if constexpr ((FEAT & FEAT_GGX) == 0) {
+        {
             // row N: one grid pass per end point of the pair (sensor-leg visibility bits first, then the
             // laser pass that ANDs them and bins)
             if (a.vis2 && !a.mode_intensity) {

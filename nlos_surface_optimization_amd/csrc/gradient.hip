@@ -136,7 +136,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                                                  a.sc.vertex_normal, a.sc.albedo, gc, tA, tB))
                             continue;
                         GVec gv;
-                        grad_vectors_nc<FEAT>(f, gc, on, onb, a.normal_term, gv);
+                        grad_vectors_nc<FEAT>(f, gc, on, onb, a.normal_term, a.sp.ggx_alpha, gv);
                         const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
                         const V3 ce[3] = {cross(gv.t2, e0), cross(gv.t2, e1), cross(gv.t2, e2)};
                         double s0, s1;
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
                                                  kbase + (uint64_t)((wi << 5) + bit), a.sp.lb, a.sp.ub, a.sc.vertex_normal,
                                                  a.sc.albedo, gc, tA, tB))
                             continue;
-                        grad_vectors_nc<FEAT>(f, gc, on, ld3(a.src.sensor_normal + 3 * (size_t)l), a.normal_term, gv);
+                        grad_vectors_nc<FEAT>(f, gc, on, ld3(a.src.sensor_normal + 3 * (size_t)l), a.normal_term, a.sp.ggx_alpha, gv);
                         di = ((gc.dirA + gc.dirB) * 0.5f) * gv.inten_f;
                         bw[0] = gc.u; bw[1] = gc.v; bw[2] = gc.w;
                         twoh = (double)(gc.d1 + gc.d2);
@@ -494,7 +494,7 @@ void gradient_launch2(const GradientArgs& a, int grid, size_t lds, hipStream_t s
 template <int FEAT>
 void gradient_launch(const GradientArgs& a, int grid, size_t lds, hipStream_t stream, bool wide) {
     if (a.src.sensor) {
-        if constexpr ((FEAT & FEAT_GGX) == 0) {
+        {
             if (wide) {
                 note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, 0, true, 1024>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(dynamic LDS)");

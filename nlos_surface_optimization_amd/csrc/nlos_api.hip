@@ -462,7 +462,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         if (!a->sensor_normal) return fail(NLOS_ERR_ARG, "nlos_render: sensor needs sensor_normal");
         if (mode != NLOS_MODE_TRANSIENT && mode != NLOS_MODE_GRADIENT)
             return fail(NLOS_ERR_ARG, "nlos_render: non-confocal pairs support TRANSIENT and GRADIENT modes only");
-        if (a->use_ggx || !a->clamp) return fail(NLOS_ERR_ARG, "nlos_render: non-confocal pairs are Lambertian with clamped form factors");
+        if (!a->clamp) return fail(NLOS_ERR_ARG, "nlos_render: non-confocal pairs use clamped form factors");
     }
 
     DeviceGuard guard(c->device);
@@ -1086,6 +1086,41 @@ int nlos_nonconfocal_render_gradient(double* data, double* weight, float* laser,
     if (numPairs > 0 && (!sensor || !sensorNormal)) return fail(NLOS_ERR_ARG, "non-confocal render: sensor arrays are NULL");
     HostRender h;
     h.mode = NLOS_MODE_GRADIENT;
+    h.data = data; h.weight = weight;
+    h.origin = laser; h.normal = laserNormal; h.sensor = sensor; h.sensor_normal = sensorNormal; h.L = numPairs;
+    h.vertices = vertices; h.V = numVertices;
+    h.vnormal = vertexNormal; h.albedo = vertexAlbedo; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.transient = transient; h.pathlengths = pathlengths; h.gradient = gradient;
+    h.refine = refine_scale; h.sigma_bin = sigma_bin; h.testing_flag = testing_flag; h.loss_test = loss_test;
+    return host_render(h);
+}
+
+int nlos_ggx_nonconfocal_render_transient(float* laser, float* laserNormal, float* sensor, float* sensorNormal,
+                                          int numPairs, float* vertices, int numVertices, float* vertexNormal,
+                                          float* vertexAlbedo, int* triangles, int numTriangles, float alpha,
+                                          int numSamples, float lowerBound, float upperBound, float resolution,
+                                          double* transient, double* pathlengths, int refine_scale, int sigma_bin) {
+    if (numPairs > 0 && (!sensor || !sensorNormal)) return fail(NLOS_ERR_ARG, "non-confocal render: sensor arrays are NULL");
+    HostRender h;
+    h.mode = NLOS_MODE_TRANSIENT; h.use_ggx = 1; h.alpha = alpha;
+    h.origin = laser; h.normal = laserNormal; h.sensor = sensor; h.sensor_normal = sensorNormal; h.L = numPairs;
+    h.vertices = vertices; h.V = numVertices;
+    h.vnormal = vertexNormal; h.albedo = vertexAlbedo; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.transient = transient; h.pathlengths = pathlengths; h.refine = refine_scale; h.sigma_bin = sigma_bin;
+    return host_render(h);
+}
+
+int nlos_ggx_nonconfocal_render_gradient(double* data, double* weight, float* laser, float* laserNormal, float* sensor,
+                                         float* sensorNormal, int numPairs, float* vertices, int numVertices,
+                                         float* vertexNormal, float* vertexAlbedo, int* triangles, int numTriangles,
+                                         float alpha, int numSamples, float lowerBound, float upperBound,
+                                         float resolution, double* transient, double* pathlengths, double* gradient,
+                                         int refine_scale, int sigma_bin, int testing_flag, int loss_test) {
+    if (numPairs > 0 && (!sensor || !sensorNormal)) return fail(NLOS_ERR_ARG, "non-confocal render: sensor arrays are NULL");
+    HostRender h;
+    h.mode = NLOS_MODE_GRADIENT; h.use_ggx = 1; h.alpha = alpha;
     h.data = data; h.weight = weight;
     h.origin = laser; h.normal = laserNormal; h.sensor = sensor; h.sensor_normal = sensorNormal; h.L = numPairs;
     h.vertices = vertices; h.V = numVertices;

@@ -335,4 +335,40 @@ __device__ __forceinline__ float ggx_eval_nwsdiff(float a, float nw) {
     return (Dp * Gv + Gp * Dv) / 4.0f;
 }
 
+
+// GGX for a (laser, sensor) pair (row N with the GGX branch; the reference has neither a kernel nor a prototype):
+// the half-vector form of the same microfacet model,
+//     brdf(n, wa, wb) = D(n.h) G1(n.wa) G1(n.wb) / 4,   h = (wa + wb) / |wa + wb|,
+// with ggx_confocal.cpp's early-outs; it is ggx_eval() for wa == wb.  GRAD: derivatives with respect to wa, wb
+// (unconstrained) and n from D' = dD/d(n.h), G1' = dG1/d(n.w) (ggx_confocal.cpp:113-150, :176-232).
+struct GgxPair { float brdf; V3 ga, gb, gn; };
+template <bool GRAD>
+__device__ __forceinline__ GgxPair ggx_pair(float a, V3 n, V3 wa, V3 wb) {
+    GgxPair o;
+    o.brdf = 0.0f;
+    o.ga = o.gb = o.gn = mk(0.0f, 0.0f, 0.0f);
+    const float na = dot(n, wa), nb = dot(n, wb);
+    if (na <= 0 || nb <= 0) return o;
+    const V3 hv = wa + wb;
+    const float hl = sqrtf(dot(hv, hv));
+    if (!(hl > 0.0f)) return o;
+    const V3 hn = hv * (1.0f / hl);
+    const float nh = dot(n, hn);
+    if (nh <= 0) return o;
+    const float Dv = ggx_D(a, nh);
+    if (Dv == 0) return o;
+    const float Ga = ggx_G1(a, na), Gb = ggx_G1(a, nb);
+    o.brdf = Dv * Ga * Gb / 4.0f;
+    if (GRAD) {
+        const float cD = ggx_D_ndiff(a, nh) * Ga * Gb / 4.0f;
+        const float cA = Dv * ggx_G1_ndiff(a, na) * Gb / 4.0f;
+        const float cB = Dv * Ga * ggx_G1_ndiff(a, nb) / 4.0f;
+        const V3 dnh = (n - hn * nh) * (1.0f / hl);          // d(n.h)/dwa = d(n.h)/dwb
+        o.ga = (dnh * cD) + (n * cA);
+        o.gb = (dnh * cD) + (n * cB);
+        o.gn = ((hn * cD) + (wa * cA)) + (wb * cB);
+    }
+    return o;
+}
+
 }  // namespace nlos

@@ -224,7 +224,8 @@ __device__ __forceinline__ void grad_vectors(const Face& f, const Geo& g, V3 on,
 // Row N: t1 = alb (ff_b grad ff_a + ff_a grad ff_b), grad ff = (n_o c3 - n c2 - 4 dir c2 c3) / d^3;
 // normal term dI/dn projected as in the confocal rows
 template <int FEAT>
-__device__ __forceinline__ void grad_vectors_nc(const Face& f, const GeoNC& g, V3 na, V3 nb, int normal_term, GVec& out) {
+__device__ __forceinline__ void grad_vectors_nc(const Face& f, const GeoNC& g, V3 na, V3 nb, int normal_term, float alpha,
+                                                GVec& out) {
     float c2a = dot(na, g.dirA), c3a = dot(g.n, -g.dirA);
     float c2b = dot(nb, g.dirB), c3b = dot(g.n, -g.dirB);
     if (c2a < 0) c2a = 0;
@@ -243,6 +244,20 @@ __device__ __forceinline__ void grad_vectors_nc(const Face& f, const GeoNC& g, V
         gn = (g.dirA * c3b) + (g.dirB * c3a);
         gn = gn * (-(g.alb * c2a * c2b));
         gn = gn * (1.0f / ((g.d1 * g.d1) * (g.d2 * g.d2)));
+    }
+    if (FEAT & FEAT_GGX) {
+        // I = I_lambert * brdf(n, wa, wb), wx = -dirx:  dI/dp = brdf dI_l/dp + I_l (J_a^T ga + J_b^T gb) with
+        // J_x = d wx / dp = -(1 - wx wx^T) / d_x;  dI/dn = brdf dI_l/dn + I_l d brdf/dn
+        const V3 wa = -g.dirA, wb = -g.dirB;
+        const GgxPair gp = ggx_pair<true>(alpha, g.n, wa, wb);
+        const float il = out.inten_f;
+        const V3 pa = (gp.ga - wa * dot(wa, gp.ga)) * (-1.0f / g.d1);
+        const V3 pb = (gp.gb - wb * dot(wb, gp.gb)) * (-1.0f / g.d2);
+        out.t1 = (out.t1 * gp.brdf) + ((pa + pb) * il);
+        if (normal_term) gn = (gn * gp.brdf) + (gp.gn * il);
+        out.inten_f = il * gp.brdf;
+    }
+    if (normal_term) {
         float ct = dot(gn, g.n);
         gn = gn - g.n * ct;
     }

@@ -260,7 +260,7 @@ def _pairs(laser, laser_normal, sensor, sensor_normal, vertices, faces):
 
 def renderNonConfocalTransient(laser, laser_normal, sensor, sensor_normal, vertices, faces, num_sample,
                                lower_bound, upper_bound, resolution, transient, pathlengths,
-                               refine_scale=1, sigma_bin=1, vertexNormal=None, albedo=None):
+                               refine_scale=1, sigma_bin=1, vertexNormal=None, albedo=None, alpha=None):
     """transient[i] = three-bounce histogram of pair (laser[i], sensor[i]); bins floor((d1+d2-lb)/res)."""
     L = _pairs(laser, laser_normal, sensor, sensor_normal, vertices, faces)
     _check_tp(transient, pathlengths, L, _num_bins(lower_bound, upper_bound, resolution))
@@ -270,6 +270,13 @@ def renderNonConfocalTransient(laser, laser_normal, sensor, sensor_normal, verti
     if albedo is not None:
         f32(albedo, 1, "albedo")
         assert vertices.shape[0] == albedo.shape[0], "albedo nees to be Vx1"
+    if alpha is not None:            # GGX BRDF of the `ggx` module, half-vector form for the pair
+        rc = _lib.lib().nlos_ggx_nonconfocal_render_transient(
+            ptr(laser), ptr(laser_normal), ptr(sensor), ptr(sensor_normal), L, ptr(vertices), vertices.shape[0],
+            ptr(vertexNormal), ptr(albedo), ptr(faces), faces.shape[0], float(alpha), int(num_sample), lower_bound,
+            upper_bound, resolution, ptr(transient), ptr(pathlengths), int(refine_scale), int(sigma_bin))
+        _lib.check(rc, "ggx_nonconfocal_render_transient")
+        return
     rc = _lib.lib().nlos_nonconfocal_render_transient(
         ptr(laser), ptr(laser_normal), ptr(sensor), ptr(sensor_normal), L, ptr(vertices), vertices.shape[0],
         ptr(vertexNormal), ptr(albedo), ptr(faces), faces.shape[0], int(num_sample), lower_bound, upper_bound,
@@ -280,7 +287,7 @@ def renderNonConfocalTransient(laser, laser_normal, sensor, sensor_normal, verti
 def renderNonConfocalGradient(laser, laser_normal, sensor, sensor_normal, vertices, faces, num_sample,
                               lower_bound, upper_bound, resolution, transient, pathlengths, gradient, data,
                               weight, refine_scale, sigma_bin, testing_flag, loss_flag, vertexNormal=None,
-                              albedo=None):
+                              albedo=None, alpha=None):
     """Vertex gradient of sum w (data - T)^2 / L over the pairs; accumulated into `gradient` (v2 semantics)."""
     L = _pairs(laser, laser_normal, sensor, sensor_normal, vertices, faces)
     numBins = _num_bins(lower_bound, upper_bound, resolution)
@@ -293,6 +300,14 @@ def renderNonConfocalGradient(laser, laser_normal, sensor, sensor_normal, vertic
     if albedo is not None:
         f32(albedo, 1, "albedo")
         assert vertices.shape[0] == albedo.shape[0], "albedo nees to be Vx1"
+    if alpha is not None:
+        rc = _lib.lib().nlos_ggx_nonconfocal_render_gradient(
+            ptr(data), ptr(weight), ptr(laser), ptr(laser_normal), ptr(sensor), ptr(sensor_normal), L, ptr(vertices),
+            vertices.shape[0], ptr(vertexNormal), ptr(albedo), ptr(faces), faces.shape[0], float(alpha), int(num_sample),
+            lower_bound, upper_bound, resolution, ptr(transient), ptr(pathlengths), ptr(gradient),
+            int(refine_scale), int(sigma_bin), int(testing_flag), int(loss_flag))
+        _lib.check(rc, "ggx_nonconfocal_render_gradient")
+        return
     rc = _lib.lib().nlos_nonconfocal_render_gradient(
         ptr(data), ptr(weight), ptr(laser), ptr(laser_normal), ptr(sensor), ptr(sensor_normal), L, ptr(vertices),
         vertices.shape[0], ptr(vertexNormal), ptr(albedo), ptr(faces), faces.shape[0], int(num_sample),

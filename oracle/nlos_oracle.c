@@ -405,6 +405,37 @@ static float ggx_eval_nwsdiff_nw(float a, float nw) {
     float Dp = ggx_D_ndiff(a, nw);
     return (Dp * Gv + Gp * Dv) / 4.0f;
 }
+/* GGX for a (laser, sensor) pair -- row N with the GGX branch.  The reference has neither a kernel nor a prototype
+ * for it; the definition is the half-vector form of the same microfacet model,
+ *     brdf(n, wa, wb) = D(n.h) G1(n.wa) G1(n.wb) / 4,   h = (wa + wb) / |wa + wb|,
+ * with ggx_confocal.cpp's early-outs (a cosine <= 0, D below the cut-off), which is eval() for wa == wb.
+ * Derivatives with respect to wa, wb (unconstrained) and n, from D' = dD/d(n.h) and G1' = dG1/d(n.w)
+ * (ggx_confocal.cpp:113-150, :176-232). */
+typedef struct { float brdf; v3 ga, gb, gn; } ggx_pair_t;
+static void ggx_pair(float a, v3 n, v3 wa, v3 wb, int want_grad, ggx_pair_t *o) {
+    o->brdf = 0.0f; o->ga = o->gb = o->gn = mk(0, 0, 0);
+    float na = dot3(n, wa), nb = dot3(n, wb);
+    if (na <= 0 || nb <= 0) return;
+    v3 hv = add3(wa, wb);
+    float hl = sqrtf(dot3(hv, hv));
+    if (!(hl > 0.0f)) return;
+    v3 hn = scl3(hv, 1.0f / hl);
+    float nh = dot3(n, hn);
+    if (nh <= 0) return;
+    float Dv = ggx_D(a, nh);
+    if (Dv == 0) return;
+    float Ga = ggx_G1(a, na), Gb = ggx_G1(a, nb);
+    o->brdf = Dv * Ga * Gb / 4.0f;
+    if (!want_grad) return;
+    float cD = ggx_D_ndiff(a, nh) * Ga * Gb / 4.0f;
+    float cA = Dv * ggx_G1_ndiff(a, na) * Gb / 4.0f;
+    float cB = Dv * Ga * ggx_G1_ndiff(a, nb) / 4.0f;
+    v3 dnh = scl3(sub3(n, scl3(hn, nh)), 1.0f / hl);          /* d(n.h)/dwa = d(n.h)/dwb */
+    o->ga = add3(scl3(dnh, cD), scl3(n, cA));
+    o->gb = add3(scl3(dnh, cD), scl3(n, cB));
+    o->gn = add3(add3(scl3(hn, cD), scl3(wa, cA)), scl3(wb, cB));
+}
+
 float nlos_oracle_ggx_eval(float alpha, const float *n, const float *w) {
     return ggx_eval_nw(alpha, dot3(ld3(n), ld3(w)));
 }
@@ -1351,11 +1382,17 @@ static void forward_task_nc(const scene_t *sc, const float *laser, const float *
         int bin = (int)floorf(((g.d1 + g.d2) - lb) / res);
         if (bin < 0 || bin >= nbins) continue;
         float val = t.area * g.alb * ffa * ffb;
+        if (op->use_ggx) {
+            ggx_pair_t gp;
+            ggx_pair(op->ggx_alpha, g.n, neg3(g.dirA), neg3(g.dirB), 0, &gp);
+            val = val * gp.brdf;
+        }
         row[bin] += (double)val / (double)spt;
     }
 }
 
-static void grad_vectors_nc(const task_t *t, v3 bn, const geo_nc_t *g, int normal_term, gvec_t *out) {
+static void grad_vectors_nc(const task_t *t, v3 bn, const geo_nc_t *g, int normal_term, int use_ggx, float alpha,
+                            gvec_t *out) {
     float c2a = dot3(t->on, g->dirA), c3a = dot3(g->n, neg3(g->dirA));
     float c2b = dot3(bn, g->dirB), c3b = dot3(g->n, neg3(g->dirB));
     if (c2a < 0) c2a = 0;
@@ -1375,6 +1412,21 @@ static void grad_vectors_nc(const task_t *t, v3 bn, const geo_nc_t *g, int norma
         gn = add3(scl3(g->dirA, c3b), scl3(g->dirB, c3a));
         gn = scl3(gn, -(g->alb * c2a * c2b));
         gn = scl3(gn, 1.0f / ((g->d1 * g->d1) * (g->d2 * g->d2)));
+    }
+    if (use_ggx) {
+        /* I = I_lambert * brdf(n, wa, wb), wx = -dirx:  dI/dp = brdf dI_l/dp + I_l (J_a^T ga + J_b^T gb) with
+         * J_x = d wx / dp = -(1 - wx wx^T) / d_x;  dI/dn = brdf dI_l/dn + I_l d brdf/dn */
+        ggx_pair_t gp;
+        v3 wa = neg3(g->dirA), wb = neg3(g->dirB);
+        ggx_pair(alpha, g->n, wa, wb, 1, &gp);
+        float il = (float)out->intensity;
+        v3 pa = scl3(sub3(gp.ga, scl3(wa, dot3(wa, gp.ga))), -1.0f / g->d1);
+        v3 pb = scl3(sub3(gp.gb, scl3(wb, dot3(wb, gp.gb))), -1.0f / g->d2);
+        t1 = add3(scl3(t1, gp.brdf), scl3(add3(pa, pb), il));
+        if (normal_term) gn = add3(scl3(gn, gp.brdf), scl3(gp.gn, il));
+        out->intensity = (double)(il * gp.brdf);
+    }
+    if (normal_term) {
         float ct = dot3(gn, g->n);
         gn = sub3(gn, scl3(g->n, ct));
     }
@@ -1405,7 +1457,7 @@ static void gradient_task_nc(const scene_t *sc, const float *laser, const float 
          * the confocal expressions vanish by themselves through their c2*c3 factor) */
         if (!(emax0(-dot3(g.n, g.dirA) * dot3(t.on, g.dirA) / g.d1 / g.d1) > 0.0f)) continue;
         if (!(emax0(-dot3(g.n, g.dirB) * dot3(bn, g.dirB) / g.d2 / g.d2) > 0.0f)) continue;
-        grad_vectors_nc(&t, bn, &g, normal_term, &gv);
+        grad_vectors_nc(&t, bn, &g, normal_term, op->use_ggx, op->ggx_alpha, &gv);
         const float bw[3] = {g.u, g.v, g.w};
         const v3 ce[3] = {cross3(gv.t2, e0), cross3(gv.t2, e1), cross3(gv.t2, e2)};
         const v3 dsum = add3(g.dirA, g.dirB);
@@ -1444,7 +1496,7 @@ int nlos_oracle_render_nonconfocal(const double *data, const double *weight,
                                    const nlos_oracle_opts *opts) {
     nlos_oracle_opts dflt;
     if (!opts) { nlos_oracle_default_opts(&dflt); opts = &dflt; }
-    if (nF <= 0 || P < 0 || refine < 1 || sigma_bin < 1 || opts->use_ggx) return -1;
+    if (nF <= 0 || P < 0 || refine < 1 || sigma_bin < 1) return -1;
     scene_t sc;
     if (scene_init(&sc, V, nV, F, nF, opts->accel)) return -1;
     const int nbins = nlos_oracle_num_bins(lb, ub, res);

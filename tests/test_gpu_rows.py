@@ -490,6 +490,50 @@ def test_nonconfocal_pairs_vs_oracle(bunny, orc, variant):
         assert rel_l2(tr2, t0) <= 1e-12
 
 
+@pytest.mark.parametrize("shading", [False, True])
+def test_nonconfocal_pairs_with_ggx_vs_oracle(bunny, orc, shading):
+    """Row N with the GGX branch (half-vector BRDF D(n.h) G1(n.wa) G1(n.wb) / 4): host entries
+    nlos_ggx_nonconfocal_render_*, grid passes and BVH back-end against the oracle; sensor == laser gives the
+    confocal GGX rows."""
+    import torch
+    from nlos_surface_optimization_amd import device as nd, renderer
+    v, f = bunny
+    a, na, b, nb = _nc_pairs()
+    ns, alpha = 20000, 0.3
+    vn = vertex_normals(v, f) if shading else None
+    tf = 0 if shading else 1
+    t0, _, _ = orc.render_nonconfocal(a, na, b, nb, v, f, ns, LB, UB, RES, vnormal=vn, accel=1, refine=1, ggx_alpha=alpha)
+    rs = np.random.RandomState(6)
+    data = t0 * (1 + 0.3 * rs.standard_normal(t0.shape))
+    w = 0.5 + rs.random_sample(t0.shape)
+    t_ref, g_ref, _ = orc.render_nonconfocal(a, na, b, nb, v, f, ns, LB, UB, RES, data=data, weight=w, refine=10,
+                                             sigma_bin=1, testing_flag=tf, vnormal=vn, accel=1, ggx_alpha=alpha)
+    L = a.shape[0]
+    tr, path, grad = np.zeros((L, T)), np.zeros(T), np.zeros((v.shape[0], 3))
+    renderer.renderNonConfocalGradient(a, na, b, nb, v, f, ns, LB, UB, RES, tr, path, grad, data, w, 10, 1, tf, 0,
+                                       vertexNormal=vn, alpha=alpha)
+    assert t_ref.sum() > 0 and np.abs(g_ref).max() > 0
+    assert rel_l2(tr, t_ref) <= 1e-5 and np.abs(tr - t_ref).max() <= 1e-6 * t_ref.max()
+    assert rel_l2(grad, g_ref) <= 1e-4
+    tr2, path2 = np.zeros((L, T)), np.zeros(T)
+    renderer.renderNonConfocalTransient(a, na, b, nb, v, f, ns, LB, UB, RES, tr2, path2, vertexNormal=vn, alpha=alpha)
+    assert rel_l2(tr2, t0) <= 1e-5
+    # device path: grid passes == BVH back-end; sensor == laser == the confocal GGX rows
+    dev = torch.device("cuda", 0)
+    r = nd.TransientRenderer(dev)
+    ta, tna, tb, tnb, tv, tf_ = (torch.from_numpy(x).to(dev) for x in (a, na, b, nb, v, f))
+    tvn = None if vn is None else torch.from_numpy(vn).to(dev)
+    g1, _ = r.render_transient(ta, tna, tv, tf_, ns, LB, UB, RES, sensor=tb, sensor_normal=tnb, alpha=alpha, vertex_normal=tvn)
+    assert r.last_path()["backend"] == "grid"
+    g2, _ = r.render_transient(ta, tna, tv, tf_, ns, LB, UB, RES, sensor=tb, sensor_normal=tnb, alpha=alpha, vertex_normal=tvn,
+                               force_bvh=True)
+    assert rel_l2(g1.cpu().numpy(), t0) <= 1e-5 and (g1 - g2).abs().max().item() <= 1e-13 * g2.max().item()
+    c0, _ = r.render_transient(ta, tna, tv, tf_, ns, LB, UB, RES, alpha=alpha, vertex_normal=tvn)
+    c1, _ = r.render_transient(ta, tna, tv, tf_, ns, LB, UB, RES, sensor=ta, sensor_normal=tna, alpha=alpha, vertex_normal=tvn)
+    assert c0.sum().item() > 0 and rel_l2(c1.cpu().numpy(), c0.cpu().numpy()) <= 1e-5
+    r.close()
+
+
 def test_nonconfocal_equals_confocal_when_sensor_is_laser(bunny):
     """sensor == laser reproduces the confocal rows: the BVH path of both kernels accepts the same
     samples, so the transients are identical up to fp64 summation order."""

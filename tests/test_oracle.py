@@ -373,6 +373,49 @@ def test_nonconfocal_gradient_against_finite_differences(orc):
     assert rel_l2(g, fd) < 0.02, (rel_l2(g, fd), g, fd)     # 0.9 % here; 0.3 % at refine 48, sigma_bin 8
 
 
+def test_nonconfocal_ggx_reduces_to_confocal_and_matches_finite_differences(orc, bunny):
+    """GGX for (laser, sensor) pairs: brdf = D(n.h) G1(n.wa) G1(n.wb) / 4 with the half vector h.  (a) sensor ==
+    laser gives the confocal GGX rows (ggx/transient_and_gradient.cpp:236; h = w up to rounding); (b) the analytic
+    vertex gradient matches central differences of the Gaussian-smoothed loss (the confocal GGX gradient mirrors the reference's BRDF_dx, whose first term lacks the 1/h of the chain
+    rule, so it is the pair formula -- derived here, no reference exists -- that is checked against differences)."""
+    v, f = bunny
+    origin, normal = grid_sources(2, 0.2)
+    lb, ub, res, ns = 0.625, 1.625, 2.0 ** -9, 20000
+    for alpha in (0.15, 0.5):
+        t0, _ = orc.render_transient(origin, normal, v, f, ns, lb, ub, res, ggx_alpha=alpha, accel=1)
+        t1, _, _ = orc.render_nonconfocal(origin, normal, origin, normal, v, f, ns, lb, ub, res, refine=1, ggx_alpha=alpha, accel=1)
+        assert t0.sum() > 0 and rel_l2(t1, t0) < 1e-5
+    v3 = np.array([[-.11, -.07, .42], [.12, -.09, .47], [.02, .13, .40]], np.float32)
+    f3 = np.array([[0, 2, 1]], np.int32)
+    a = np.array([[0.05, -0.02, 0], [-0.15, 0.1, 0]], np.float32)
+    b = np.array([[-0.12, 0.08, 0], [0.2, -0.05, 0]], np.float32)
+    n = np.tile(np.array([0, 0, 1], np.float32), (2, 1))
+    lb, ub, res, ns = 0.5, 1.5, 2.0 ** -6, 1024
+    R, SB = 24, 5
+    rs = np.random.RandomState(3)
+    data = rs.random_sample((2, 64)) * 0.02
+    w = 0.5 + rs.random_sample((2, 64))
+    for alpha in (0.3, 0.8):         # face normals, normal term on: the setting in which differences validate the formulas (SURVEY Q1)
+        kw = dict(ggx_alpha=alpha, threads=1)
+
+        def loss(vv):
+            t, _, _ = orc.render_nonconfocal(a, n, b, n, vv, f3, ns, lb, ub, res, refine=R, sigma_bin=SB, **kw)
+            return float(np.sum(w * (data - t) ** 2) / a.shape[0])
+
+        _, g, _ = orc.render_nonconfocal(a, n, b, n, v3, f3, ns, lb, ub, res, data=data, weight=w, refine=R,
+                                         sigma_bin=SB, testing_flag=0, normal_term=1, **kw)
+        fd = np.zeros((3, 3))
+        eps = 1e-3
+        for i in range(3):
+            for c in range(3):
+                vp, vm = v3.astype(np.float64).copy(), v3.astype(np.float64).copy()
+                vp[i, c] += eps
+                vm[i, c] -= eps
+                fd[i, c] = (loss(vp.astype(np.float32)) - loss(vm.astype(np.float32))) / (
+                    float(np.float32(vp[i, c])) - float(np.float32(vm[i, c])))
+        assert np.abs(fd).max() > 0 and rel_l2(g, fd) < 0.02, (alpha, rel_l2(g, fd), g, fd)    # 0.8 % / 0.6 %
+
+
 # ------------------------------------------------------------------ jitter/ module (SURVEY 8f rank 1)
 def test_jitter_forward_is_histogram_convolved_with_kernel(orc, bunny):
     """jitter/transient_and_gradient.cpp:331-347 on the reference's own measured kernel
