@@ -724,7 +724,6 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
 #endif
     uint32_t* wq = s_queue + wave * (kQueueCap + 1);     // this wave's pair queue (aliases the build-phase tables) + dump slot
     uint32_t* wocc = s_queue + nwaves * (kQueueCap + 1) + wave * 2;  // this wave's 64-bit occlusion mask
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     // GRID (workgroup-uniform): occlusion through the cell lists; otherwise (scene not strictly in front of the
     // wall point, or lists that fit nowhere) every ray runs the stackless BVH query.  Two instances of the loop,
@@ -874,12 +873,16 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 if (grid_ray) c_rays += 1;
 #endif
                 constexpr uint32_t imask = (1u << IB) - 1u;
-                auto push = [&](bool pass, uint32_t w) {
-                    const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+                // `m` is the wave's 64-bit mask of the lanes that append (an SGPR pair straight out of the compares: the
+                // ballot of a boolean that was AND-ed together costs a v_cndmask + v_cmp per slot on this compiler).
+                auto push = [&](unsigned long long m, uint32_t w) {
                     if (m) {
-                        // every lane stores (the ones that append nothing into the dump slot): a select instead of a
-                        // divergent region, so the compare mask feeds the ballot and the select directly
-                        wq[pass ? qn + __popcll(m & lt_mask) : kQueueCap] = ((uint32_t)lane << 16) | (w & imask);
+                        // every lane stores -- the ones that append nothing into the dump slot: a select on the mask
+                        // instead of a divergent region
+                        const uint32_t at = (uint32_t)qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        uint32_t slot;
+                        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(slot) : "v"((uint32_t)kQueueCap), "v"(at), "s"(m));
+                        wq[slot] = ((uint32_t)lane << 16) | (w & imask);
                         qn += __popcll(m);
                         if (qn >= kRound) {
                             TACC(ts);
@@ -898,25 +901,27 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 // (the two bits of rmask lie above the index field, so a word that misses one of them stays below rmask
                 // whatever its index) -- four VALU operations per entry instead of six.
                 const uint32_t jx = (uint32_t)j, m2 = rmask | imask;
+                constexpr int kULT = 36, kULE = 37, kUGT = 34;       // llvm.amdgcn.icmp predicates
                 // kScan entries per trip: the lockstep walk pays its loop overhead (any(), branch, counters) once per
                 // trip; lists average 24 entries, so wider trips waste more slots at the end (2: 2.49 ms, 4: 2.43 ms)
                 while (__any(e < e1)) {
                     // every lane reads its next kScan words (finished lanes re-read the slots behind their list and
-                    // fail the range term): no divergent region, so the ballots below are the compare masks themselves
+                    // fail the range term): no divergent region, the compare masks are combined on the scalar unit
                     const uint32_t rem = e < e1 ? e1 - e : 0u;
-                    bool p[kScan];
+                    unsigned long long p[kScan];
                     uint32_t w[kScan];
 #pragma unroll
                     for (int q = 0; q < kScan; ++q) {
                         w[q] = s_ent[e + q];
                         const uint32_t x = w[q] ^ jx;
-                        p[q] = ((uint32_t)q < rem) & (x <= rlim) & ((x & m2) > rmask);
+                        p[q] = __builtin_amdgcn_uicmp((uint32_t)q, rem, kULT) & __builtin_amdgcn_uicmp(x, rlim, kULE) &
+                               __builtin_amdgcn_uicmp(x & m2, rmask, kUGT);
                     }
 #ifdef NLOS_FWD_STAMPS
                     if (grid_ray) c_pairs += min((uint32_t)kScan, rem);
                     if (lane == 0) c_iters += 1;
 #pragma unroll
-                    for (int q = 0; q < kScan; ++q) if (p[q]) c_mt += 1;
+                    for (int q = 0; q < kScan; ++q) if ((p[q] >> lane) & 1ull) c_mt += 1;
 #endif
                     e += min((uint32_t)kScan, rem);
 #pragma unroll
