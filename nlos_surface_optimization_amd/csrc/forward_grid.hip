@@ -444,7 +444,11 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 uint32_t* visp = visout + ((size_t)l * a.vis_words) * F + j;
                 for (int wi = 0; wi < a.vis_words; ++wi) visp[(size_t)wi * F] = 0u;
             }
+#ifdef NLOS_DIAG_NO_ZC             // diagnostic builds only
+            if (false) {
+#else
             if (live && frame_ok && !(TILED && ident)) {
+#endif
                 const float zfar = fmaxf(fmaxf(f.p0.z, f.p1.z), f.p2.z) - o.z;
                 const uint32_t zb = __float_as_uint(fmaxf(zfar, 0.0f) * 1.0001f + 1e-30f);
                 const Proj2 q = project_tri(o, f.p0, f.p1, f.p2);
@@ -497,7 +501,11 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
         }
         if (frame_ok && !(TILED && ident)) {
             // ---- counting pass -----------------------------------------------------------------------
+#ifdef NLOS_DIAG_NO_COUNT          // diagnostic builds only (tools/ab_pmc.sh)
+            for (int jl = Fl; jl < Fl; jl += NT) {
+#else
             for (int jl = tid; jl < Fl; jl += NT) {
+#endif
                 const int j = gid(jl);
                 const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
                 const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
@@ -573,7 +581,11 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     unsigned long long nib0 = 0ull, nib1 = 0ull;
     if (frame_ok && s_ctl[1] == 0) {
         int it = 0;
+#ifdef NLOS_DIAG_NO_FILL           // diagnostic builds only
+        for (int jl = Fl; jl < Fl; jl += NT, ++it) {
+#else
         for (int jl = tid; jl < Fl; jl += NT, ++it) {
+#endif
             // what the counting pass found: nothing to enter (about half of the triangles: the far side of the
             // object), a mask of up to 4 x 4 cells, or a large bounding box that is rasterised again
             const uint32_t cov = g_cov[jl];
@@ -1027,14 +1039,35 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
 #ifndef NLOS_GRID_RSCALE
 #define NLOS_GRID_RSCALE 0.5f
 #endif
+    // finer cells shorten the per-sample walk for as long as the cell lists still fit: R = sqrt(F/2) always, and up to
+    // sqrt(NLOS_GRID_RSCALE_MAX F) while a worst-case estimate of the entry count (each reachable face covering
+    // (1 + 1.38 R/sqrt F)^2 cells, 70 % of the faces reachable, 30 % margin; calibrated on where bunny_5k starts to overflow)
+    // stays below the capacity that resolution leaves.  Measured at 1 055 faces: forward 2.08 -> 1.93 ms.
+#ifndef NLOS_GRID_RSCALE_MAX
+#define NLOS_GRID_RSCALE_MAX 1.6f
+#endif
+    const size_t nblk = ((size_t)a.sc.F + 63) / 64;
+    auto fixed_bytes = [&](int r) {
+        const size_t r2 = ((size_t)r + 1) / 2;
+        size_t union_words = ((r2 * r2 + 1) & ~(size_t)1) + 2 * nblk;
+        if (union_words < (size_t)kGridWaves * kQueueWords) union_words = (size_t)kGridWaves * kQueueWords;
+        return 32 + (rows_in_lds ? (size_t)a.sp.nbins * sizeof(double) : 0) + (((size_t)r * r + 2) & ~(size_t)1) * 4 +
+               ((union_words + 1) & ~(size_t)1) * 4;
+    };
     int R = (int)lrintf(sqrtf(NLOS_GRID_RSCALE * (float)a.sc.F));
     R = std::min(std::max(R, 8), 96);
-    const size_t nblk = ((size_t)a.sc.F + 63) / 64;
-    const size_t R2 = ((size_t)R + 1) / 2;
-    size_t union_words = ((R2 * R2 + 1) & ~(size_t)1) + 2 * nblk;
-    if (union_words < (size_t)kGridWaves * kQueueWords) union_words = (size_t)kGridWaves * kQueueWords;
-    const size_t fixed = 32 + (rows_in_lds ? (size_t)a.sp.nbins * sizeof(double) : 0) + (((size_t)R * R + 2) & ~(size_t)1) * 4 +
-                         ((union_words + 1) & ~(size_t)1) * 4;
+    {
+        const int r_hi = std::min((int)lrintf(sqrtf(NLOS_GRID_RSCALE_MAX * (float)a.sc.F)), 96);
+        const float sf = sqrtf((float)a.sc.F);
+        for (int r = r_hi; r > R; --r) {
+            const size_t fx = fixed_bytes(r);
+            if (fx >= kGridLdsBudget) continue;
+            const float per_face = 1.f + 1.38f * (float)r / sf;
+            const float est = 1.3f * 0.7f * (float)a.sc.F * per_face * per_face;
+            if (est <= (float)((kGridLdsBudget - fx) / 4)) { R = r; break; }
+        }
+    }
+    const size_t fixed = fixed_bytes(R);
     if (fixed + 4 * 2 * (size_t)a.sc.F > kGridLdsBudget || !a.live || !a.cov) { note.reason = 3; return false; }   // want room for >= 2 entries per face
     size_t cap = (kGridLdsBudget - fixed) / 4;
     const size_t lds = fixed + cap * 4;
