@@ -439,7 +439,11 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             load_face_tri<FEAT>(a.sc, jg, f, tr_unused);
             const bool dark = face_dark(f);
             live = !dark;
+#ifdef NLOS_DIAG_NO_DARKZERO       // diagnostic builds only
+            if (false) {
+#else
             if (!TILED && dark && visout) {
+#endif
                 // dark faces: no sample is ever accepted (live faces receive their words from the trace)
                 uint32_t* visp = visout + ((size_t)l * a.vis_words) * F + j;
                 for (int wi = 0; wi < a.vis_words; ++wi) visp[(size_t)wi * F] = 0u;
@@ -743,6 +747,24 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     // vertex lies in front of the wall point, hence dir.z > 0 for every ray of the grid loop.
     auto trace = [&](auto grid_c) {
         constexpr bool GRID = decltype(grid_c)::value;
+        // The accepted-sample words of an item are written one item LATER, right after that item's face records have
+        // been requested: a store counts in vmcnt like the loads, in order, so the wait for the next loads after a
+        // store also waits for the store's acknowledgement from the L2 -- with the store at the end of the item every
+        // wave stalled for it before it could start the next item (measured without the stores: 12 % of the kernel on
+        // the bunny, 34 % on the 1 055-face mannequin, for 1.7 % of the instructions).  Behind the loads the two
+        // latencies overlap: forward 1.84 -> 1.75 ms (bunny), 1.92 -> 1.60 ms (mannequin).  (Issued after the records
+        // have been consumed, or after the sample arithmetic, it is no faster: measured.)  pend_at: word offset within the source's rows, bit 31 = OR the piece in (a word shared
+        // with another item or tile) instead of storing it; ~0 = nothing pending.
+        uint32_t pend_at = ~0u, pend_bits = 0u;
+        uint32_t* const vrow = visout ? visout + (size_t)l * a.vis_words * F : nullptr;
+        auto flush_pending = [&]() {
+            if (pend_at != ~0u) {
+                uint32_t* wp = vrow + (pend_at & 0x7FFFFFFFu);
+                if (pend_at & 0x80000000u) atomicOr(wp, pend_bits);
+                else *wp = pend_bits;
+            }
+            pend_at = ~0u;
+        };
         for (;;) {
             const int b = wave_ticket(&s_ctl[0]);
             if (b >= n_items) break;
@@ -756,6 +778,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             Face f;
             Tri tr;
             load_face_tri<FEAT>(a.sc, jg, f, tr);
+            if (visout) flush_pending();                                    // the previous item's words, behind this item's loads
             if (!compact && has_ray) has_ray = !face_dark(f);               // (the block masks are gone: the queue reuses their LDS)
             if (TILED && !compact && has_ray && frame_ok) {
                 // overflowed subset: every face is visited, most of them lie outside this tile
@@ -959,7 +982,11 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     else unsafeAtomicAdd(&grow[bin], cc);
                 }
             }
+#ifdef NLOS_DIAG_NO_VIS            // diagnostic builds only (tools/ab_traffic.sh): HBM traffic without the accepted-sample words
+            if (false) {
+#else
             if (visout) {
+#endif
                 // accepted-sample bits: the strata of a (face, word) that this wave holds sit in consecutive lanes;
                 // the first of them writes the piece.  A word that lies completely inside the wave is stored (its
                 // only writer); a face that straddles two items -- or tiles -- ORs its pieces into the zeroed word.
@@ -968,13 +995,14 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     const int in_word = min(spt - s, 32 - (s & 31));                  // strata left in this word
                     const int cnt = min(in_word, 64 - lane);                          // ... of which this wave holds
                     const uint32_t bits = (uint32_t)((acc >> lane) & ((1ull << cnt) - 1ull));
-                    uint32_t* wp = visout + ((size_t)l * a.vis_words + (size_t)(s >> 5)) * F + jg;
-                    if (!TILED && (s & 31) == 0 && cnt == in_word) *wp = bits;
-                    else if (bits) atomicOr(wp, bits << (s & 31));
+                    const uint32_t at = (uint32_t)(s >> 5) * (uint32_t)F + (uint32_t)jg;
+                    if (!TILED && (s & 31) == 0 && cnt == in_word) { pend_at = at; pend_bits = bits; }
+                    else if (bits) { pend_at = at | 0x80000000u; pend_bits = bits << (s & 31); }
                 }
             }
             TACC(th);
         }
+        if (visout) flush_pending();
     };
     if (use_grid) trace(std::true_type{});
     else trace(std::false_type{});
