@@ -505,6 +505,8 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
         }
         if (frame_ok && !(TILED && ident)) {
             // ---- counting pass -----------------------------------------------------------------------
+            int pend_jl = -1;
+            uint16_t pend_cov = 0;
 #ifdef NLOS_DIAG_NO_COUNT          // diagnostic builds only (tools/ab_pmc.sh)
             for (int jl = Fl; jl < Fl; jl += NT) {
 #else
@@ -512,6 +514,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
 #endif
                 const int j = gid(jl);
                 const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
+                if (pend_jl >= 0) g_cov[pend_jl] = pend_cov;       // the previous triangle's cells, behind this one's loads (see the trace)
                 const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
                 const uint32_t zn = __float_as_uint(fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f));
                 // the cells the triangle enters are remembered for the fill pass (16 bits per triangle in global
@@ -532,8 +535,9 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     reach = reachable(zn)(cx0, cx1, cy0, cy1);
                     return reach;
                 });
-                g_cov[jl] = (uint16_t)(!reach ? 0u : big ? 0xFFFFu : cv);
+                pend_jl = jl; pend_cov = (uint16_t)(!reach ? 0u : big ? 0xFFFFu : cv);
             }
+            if (pend_jl >= 0) g_cov[pend_jl] = pend_cov;
         }
         __syncthreads();
         if (attempt == 0) FWD_STAMP();   // 1: counting pass
