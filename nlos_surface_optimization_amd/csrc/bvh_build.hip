@@ -30,7 +30,10 @@ namespace {
 constexpr int BT = 1024;          // build threads (one workgroup)
 constexpr int RBITS = 4;          // radix bits per pass
 constexpr int RDIG = 1 << RBITS;  // 16 digits: the counters (66 KB) leave room for keys and indices in LDS
-constexpr int RPASS = 8;          // 30-bit keys (an even number of passes: the result lands in the first buffer)
+constexpr int RPASS = 6;          // 24-bit keys (an even number of passes: the result lands in the first buffer)
+constexpr int QBITS = 8;          // Morton bits per axis of the single-workgroup builder (<= 5.8 k faces in 256^3 cells; the
+                                  // chip-wide front end for larger meshes keeps 10): two radix passes less
+constexpr int KF = 6;             // faces per thread the single-workgroup builder keeps in registers (F <= 6144)
 constexpr int RCNT_WORDS = RDIG * BT + RDIG * BT / 32 + 32;   // skewed counter table
 
 __device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
@@ -69,7 +72,7 @@ __device__ __forceinline__ void emit_node(const BuildArgs& a, int id, const floa
 
 // Karras (2012) radix-tree node i over the sorted keys: children, covered leaf range, parent links
 __device__ __forceinline__ void karras_node(const BuildArgs& a, const uint32_t* __restrict__ keys, int F, int i,
-                                            int& left, int& right) {
+                                            int& left, int& right, int& last_out) {
     const int n_int = F - 1;
     int d = (delta(keys, F, i, i + 1) - delta(keys, F, i, i - 1)) >= 0 ? 1 : -1;
     int dmin = delta(keys, F, i, i - d);
@@ -93,6 +96,7 @@ __device__ __forceinline__ void karras_node(const BuildArgs& a, const uint32_t* 
     a.child[2 * i + 1] = right;
     a.range[2 * i] = first;
     a.range[2 * i + 1] = last;
+    last_out = last;
     a.parent[left] = i;
     a.parent[right] = i;
     a.arrive[i] = 0;
@@ -105,6 +109,43 @@ __device__ __forceinline__ int escape_link(const BuildArgs& a, int F, int last) 
     if (s >= F) return -1;
     if (s < n_int && a.range[2 * s] == s) return s;      // inner node s starts at leaf s
     return n_int + s;                                    // otherwise the leaf itself
+}
+
+// the three vertex indices of face f, clamped without side effects (the caller reports `bad` once): loads that are
+// followed by a possible atomic cannot be hoisted over one another, and a chain of dependent loads per face is what
+// the single-workgroup builder spends its time on
+__device__ __forceinline__ void face_indices(const BuildArgs& a, int f, int (&vi)[3], bool& bad) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int v = a.faces[3 * f + q];
+        const bool ok = (unsigned)v < (unsigned)a.V;
+        bad = bad || !ok;
+        vi[q] = ok ? v : 0;
+    }
+}
+
+// leaf_records() from vertices already in registers
+__device__ __forceinline__ void leaf_records_from(const BuildArgs& a, int j, int f, const int (&vi)[3], V3 p0, V3 p1, V3 p2, float pad,
+                                                  float (&lb6)[6]) {
+    const int i0 = vi[0], i1 = vi[1], i2 = vi[2];
+    Tri tr = make_tri(p0, p1, p2);
+    a.tris[kTriStride * j] = make_float4(tr.p0.x, tr.p0.y, tr.p0.z, tr.e1.x);
+    a.tris[kTriStride * j + 1] = make_float4(tr.e1.y, tr.e1.z, tr.e2.x, tr.e2.y);
+    a.tris[kTriStride * j + 2] = make_float4(tr.e2.z, tr.ng.x, tr.ng.y, tr.ng.z);
+    const float area = sqrtf(dot(tr.ng, tr.ng)) / 2.0f;
+    a.tris[kTriStride * j + 3] = make_float4(fminf(fminf(p0.z, p1.z), p2.z), __int_as_float(f), area, 1.0f / (2.0f * area));
+    a.facerec[4 * j] = make_float4(p0.x, p0.y, p0.z, p1.x);
+    a.facerec[4 * j + 1] = make_float4(p1.y, p1.z, p2.x, p2.y);
+    a.facerec[4 * j + 2] = make_float4(p2.z, __int_as_float(f), __int_as_float(i0), __int_as_float(i1));
+    a.facerec[4 * j + 3] = make_float4(__int_as_float(i2), 0.0f, 0.0f, 0.0f);
+    a.face_id[j] = f;
+    a.tri_zmin[j] = fminf(fminf(p0.z, p1.z), p2.z);
+    lb6[0] = fminf(fminf(p0.x, p1.x), p2.x) - pad;
+    lb6[1] = fminf(fminf(p0.y, p1.y), p2.y) - pad;
+    lb6[2] = fminf(fminf(p0.z, p1.z), p2.z) - pad;
+    lb6[3] = fmaxf(fmaxf(p0.x, p1.x), p2.x) + pad;
+    lb6[4] = fmaxf(fmaxf(p0.y, p1.y), p2.y) + pad;
+    lb6[5] = fmaxf(fmaxf(p0.z, p1.z), p2.z) + pad;
 }
 
 // triangle / face records of sorted slot j and its padded box
@@ -279,7 +320,8 @@ __global__ __launch_bounds__(256) void k_build_tree(BuildArgs a) {
     if (i == 0) a.parent[F > 1 ? 0 : n_int] = -1;
     if (i >= n_int) return;
     int left, right;
-    karras_node(a, a.keys0, F, i, left, right);
+    int last_unused;
+    karras_node(a, a.keys0, F, i, left, right, last_unused);
 }
 
 __global__ __launch_bounds__(256) void k_build_refit(BuildArgs a) {
@@ -337,8 +379,38 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, 
 #endif
 
     // ---- phase 1: scene bounds --------------------------------------------------
+    // Faces tid + k * BT, k < KF, are read once: their centroid sums stay in registers for the Morton keys (the loop
+    // is unrolled, so the index and vertex loads of all k are in flight together instead of one dependent chain per
+    // face and phase: 36 k -> ~14 k cycles for both phases at F = 5 k).
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    for (int f = tid; f < F; f += BT) {
+    float csum[KF][3];
+    const bool in_regs = F <= KF * BT;
+    bool bad_index = false;
+    {
+        int vi[KF][3];
+#pragma unroll
+        for (int k = 0; k < KF; ++k) {
+            const int f = tid + k * BT;
+            vi[k][0] = vi[k][1] = vi[k][2] = 0;
+            if (in_regs && f < F) face_indices(a, f, vi[k], bad_index);
+        }
+#pragma unroll
+        for (int k = 0; k < KF; ++k) {
+            const int f = tid + k * BT;
+            csum[k][0] = csum[k][1] = csum[k][2] = 0.0f;
+            if (in_regs && f < F) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const V3 x = ld3(a.vertices + 3 * (size_t)vi[k][q]);
+                    lo[0] = fminf(lo[0], x.x); hi[0] = fmaxf(hi[0], x.x); csum[k][0] += x.x;
+                    lo[1] = fminf(lo[1], x.y); hi[1] = fmaxf(hi[1], x.y); csum[k][1] += x.y;
+                    lo[2] = fminf(lo[2], x.z); hi[2] = fmaxf(hi[2], x.z); csum[k][2] += x.z;
+                }
+            }
+        }
+    }
+    if (bad_index) atomicOr(a.status, 1);
+    for (int f = tid; !in_regs && f < F; f += BT) {
         for (int k = 0; k < 3; ++k) {
             int vi = clamp_index(a.faces[3 * f + k], a.V, a.status);
             for (int c = 0; c < 3; ++c) {
@@ -387,19 +459,33 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, 
     {
         float sx = s_bounds[3] - s_bounds[0], sy = s_bounds[4] - s_bounds[1], sz = s_bounds[5] - s_bounds[2];
         float ix = sx > 0 ? 1.0f / sx : 0.0f, iy = sy > 0 ? 1.0f / sy : 0.0f, iz = sz > 0 ? 1.0f / sz : 0.0f;
-        for (int f = tid; f < F; f += BT) {
+        // 2^QBITS cells per axis while the registers hold the faces (always, with today's launcher: the LDS refit
+        // bounds this kernel to 5.8 k faces), else the 10 bits of the generic loops
+        auto morton = [&](float cx, float cy, float cz, float cells) -> uint32_t {
+            float nx = (cx * (1.0f / 3.0f) - s_bounds[0]) * ix;
+            float ny = (cy * (1.0f / 3.0f) - s_bounds[1]) * iy;
+            float nz = (cz * (1.0f / 3.0f) - s_bounds[2]) * iz;
+            uint32_t qx = (uint32_t)fminf(fmaxf(nx * cells, 0.0f), cells - 1.0f);
+            uint32_t qy = (uint32_t)fminf(fmaxf(ny * cells, 0.0f), cells - 1.0f);
+            uint32_t qz = (uint32_t)fminf(fmaxf(nz * cells, 0.0f), cells - 1.0f);
+            return (expand_bits(qx) << 2) | (expand_bits(qy) << 1) | expand_bits(qz);
+        };
+#pragma unroll
+        for (int k = 0; k < KF; ++k) {
+            const int f = tid + k * BT;
+            if (in_regs && f < F) {
+                const uint32_t key = morton(csum[k][0], csum[k][1], csum[k][2], (float)(1 << QBITS));
+                if (sort_in_lds) { s_keyA[f] = key; s_idxA[f] = (uint16_t)f; }
+                else { a.keys0[f] = key; a.idx0[f] = f; }
+            }
+        }
+        for (int f = tid; !in_regs && f < F; f += BT) {
             float c[3] = {0, 0, 0};
             for (int k = 0; k < 3; ++k) {
                 int vi = clamp_index(a.faces[3 * f + k], a.V, a.status);
                 for (int q = 0; q < 3; ++q) c[q] += a.vertices[3 * (size_t)vi + q];
             }
-            float nx = (c[0] * (1.0f / 3.0f) - s_bounds[0]) * ix;
-            float ny = (c[1] * (1.0f / 3.0f) - s_bounds[1]) * iy;
-            float nz = (c[2] * (1.0f / 3.0f) - s_bounds[2]) * iz;
-            uint32_t qx = (uint32_t)fminf(fmaxf(nx * 1024.0f, 0.0f), 1023.0f);
-            uint32_t qy = (uint32_t)fminf(fmaxf(ny * 1024.0f, 0.0f), 1023.0f);
-            uint32_t qz = (uint32_t)fminf(fmaxf(nz * 1024.0f, 0.0f), 1023.0f);
-            const uint32_t key = (expand_bits(qx) << 2) | (expand_bits(qy) << 1) | expand_bits(qz);
+            const uint32_t key = morton(c[0], c[1], c[2], 1024.0f);
             if (sort_in_lds) { s_keyA[f] = key; s_idxA[f] = (uint16_t)f; }
             else { a.keys0[f] = key; a.idx0[f] = f; }
         }
@@ -412,7 +498,7 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, 
     const int chunk = (F + BT - 1) / BT;
     const int c0 = min(tid * chunk, F), c1 = min(c0 + chunk, F);
     auto radix_sort = [&](auto* keys_in, auto* keys_out, auto* idx_in, auto* idx_out) {
-        for (int pass = 0; pass < RPASS; ++pass) {
+        for (int pass = 0; pass < (in_regs ? RPASS : 8); ++pass) {        // 3 * QBITS-bit keys, or the 30 bits of the generic loop
             const int shift = pass * RBITS;
             for (int d = 0; d < RDIG; ++d) s_cnt[SK(d * BT + tid)] = 0;
             for (int i = c0; i < c1; ++i) s_cnt[SK(((keys_in[i] >> shift) & (RDIG - 1)) * BT + tid)] += 1;
@@ -473,9 +559,26 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, 
     // binary searches of the tree construction read them there; the boxes are initialised afterwards.
     const uint32_t* tree_keys = sort_in_lds ? s_keyA : keys;
     if (lds_refit && tid == 0) s_par[0] = 0x7FFFFFFFu;  // root: no parent
-    for (int i = tid; i < n_int; i += BT) {
-        int left, right;
-        karras_node(a, tree_keys, F, i, left, right);
+    // staged = the common case (LDS refit, faces in registers): nodes tid + k * BT keep their left child and the end of
+    // their leaf range in registers for the node emission below
+    const bool staged = lds_refit && in_regs;
+    int nd_left[KF], nd_last[KF];
+#pragma unroll
+    for (int k = 0; k < KF; ++k) {
+        const int i = tid + k * BT;
+        nd_left[k] = nd_last[k] = 0;
+        if (staged && i < n_int) {
+            int left, right, last;
+            karras_node(a, tree_keys, F, i, left, right, last);
+            if (left < n_int) s_par[left] = (uint32_t)i;
+            if (right < n_int) s_par[right] = (uint32_t)i;
+            nd_left[k] = left;
+            nd_last[k] = last;
+        }
+    }
+    for (int i = tid; !staged && i < n_int; i += BT) {
+        int left, right, last_unused;
+        karras_node(a, tree_keys, F, i, left, right, last_unused);
         if (lds_refit) {
             if (left < n_int) s_par[left] = (uint32_t)i;
             if (right < n_int) s_par[right] = (uint32_t)i;
@@ -493,6 +596,79 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, 
     auto escape_of = [&](int last) -> int { return escape_link(a, F, last); };
 
     // ---- phase 5: leaf records + bottom-up refit + node emission -------------------------
+    if (staged) {
+        // Leaves tid + k * BT: every round of dependent loads (order -> indices -> vertices; parents and escape links
+        // beside them) is issued for all k before anything is stored -- a store between two rounds would be waited for
+        // with the loads behind it (vmcnt is in order), and the generic loop below walked one dependent chain per leaf:
+        // 108 k -> ~60 k cycles for this phase at F = 5 k.
+        constexpr int KH = 3;                    // leaves per batch: three dependent rounds of loads per batch, 45 registers
+        bool bad = false;
+#pragma unroll 1
+        for (int h = 0; h < KF; h += KH) {
+            int fo[KH], par[KH], esc[KH], vi[KH][3];
+#pragma unroll
+            for (int k = 0; k < KH; ++k) {
+                const int j = tid + (h + k) * BT;
+                fo[k] = 0; par[k] = -1; esc[k] = -1;
+                if (j < F) {
+                    fo[k] = order[j];
+                    par[k] = F > 1 ? a.parent[n_int + j] : -1;
+                    esc[k] = escape_of(j);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KH; ++k) {
+                vi[k][0] = vi[k][1] = vi[k][2] = 0;
+                if (tid + (h + k) * BT < F) face_indices(a, fo[k], vi[k], bad);
+            }
+            V3 P[KH][3];
+#pragma unroll
+            for (int k = 0; k < KH; ++k)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    P[k][q] = (tid + (h + k) * BT < F) ? ld3(a.vertices + 3 * (size_t)vi[k][q]) : mk(0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int k = 0; k < KH; ++k) {
+                const int j = tid + (h + k) * BT;
+                if (j >= F) continue;
+                float lb6[6];
+                leaf_records_from(a, j, fo[k], vi[k], P[k][0], P[k][1], P[k][2], pad, lb6);
+                emit_node(a, n_int + j, lb6, esc[k], ~j);
+                // merge into the parent's box with LDS min/max atomics, then raise the parent's flag; the
+                // second arriver finds the box complete, takes it as its own and continues one level up
+                uint32_t key[6];
+                for (int c = 0; c < 6; ++c) key[c] = fkey(lb6[c]);
+                uint32_t node = par[k] >= 0 ? (uint32_t)par[k] : 0x7FFFFFFFu;
+                while (node != 0x7FFFFFFFu) {
+                    for (int c = 0; c < 3; ++c) atomicMin(&s_box[6 * node + c], key[c]);
+                    for (int c = 3; c < 6; ++c) atomicMax(&s_box[6 * node + c], key[c]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    const uint32_t old = atomicOr(&s_par[node], 0x80000000u);
+                    if (!(old & 0x80000000u)) break;          // sibling subtree not finished yet
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    for (int c = 0; c < 6; ++c)
+                        key[c] = __hip_atomic_load(&s_box[6 * node + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    node = old & 0x7FFFFFFFu;
+                }
+            }
+        }
+        if (bad) atomicOr(a.status, 1);
+        __syncthreads();
+        // inner nodes: the escape links first (one more load each), then the stores
+        int nesc[KF];
+#pragma unroll
+        for (int k = 0; k < KF; ++k) nesc[k] = (tid + k * BT < n_int) ? escape_of(nd_last[k]) : -1;
+#pragma unroll
+        for (int k = 0; k < KF; ++k) {
+            const int i = tid + k * BT;
+            if (i >= n_int) continue;
+            float nb[6];
+            for (int c = 0; c < 6; ++c) nb[c] = fkey_inv(s_box[6 * i + c]);
+            emit_node(a, i, nb, nesc[k], nd_left[k]);
+        }
+        NLOS_STAMP();
+        return;
+    }
     for (int j = tid; j < F; j += BT) {
         float lb6[6];
         leaf_records(a, order, j, pad, lb6);
