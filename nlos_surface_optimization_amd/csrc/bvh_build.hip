@@ -666,6 +666,11 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, 
             for (int c = 0; c < 6; ++c) nb[c] = fkey_inv(s_box[6 * i + c]);
             emit_node(a, i, nb, nesc[k], nd_left[k]);
         }
+        // the bad-index word goes to the host by a store of its own (every atomicOr on it happened before the barrier
+        // above): no copy operation behind the build in the stream
+        if (tid == 0 && a.host_status)
+            __hip_atomic_store(a.host_status, __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
         NLOS_STAMP();
         return;
     }
@@ -726,10 +731,14 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, 
             emit_node(a, i, nb, escape_of(a.range[2 * i + 1]), a.child[2 * i]);
         }
     }
+    __syncthreads();
+    if (tid == 0 && a.host_status)
+        __hip_atomic_store(a.host_status, __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
     NLOS_STAMP();
 }
 
-void launch_build_bvh(const BuildArgs& a, hipStream_t stream) {
+bool launch_build_bvh(const BuildArgs& a, hipStream_t stream) {
     // dynamic LDS: the radix counters (66 KB) + sort buffers (12 B per face), or 28 B per inner node for the LDS refit if that is more
     // and still fits beside the static arrays (160 KB per CU)
     // (radix counters + keys and 16-bit indices of the in-LDS sort)
@@ -743,7 +752,7 @@ void launch_build_bvh(const BuildArgs& a, hipStream_t stream) {
         note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_bvh), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds), "hipFuncSetAttribute(dynamic LDS)");
         hipLaunchKernelGGL(k_build_bvh, dim3(1), dim3(BT), lds, stream, a, (int)(lds / sizeof(uint32_t)), 0);
-        return;
+        return a.host_status != nullptr;
     }
     // bounds -> Morton keys -> 4 x (histogram, scan, scatter) -> tree -> refit
     uint32_t* bkeys = reinterpret_cast<uint32_t*>(a.status) + 16;          // 6 order-preserving bound keys
@@ -765,6 +774,7 @@ void launch_build_bvh(const BuildArgs& a, hipStream_t stream) {
     }
     hipLaunchKernelGGL(k_build_tree, dim3((a.F + 255) / 256), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(k_build_refit, dim3((a.F + 255) / 256), dim3(256), 0, stream, a);
+    return false;
 }
 
 }  // namespace nlos

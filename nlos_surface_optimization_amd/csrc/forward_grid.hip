@@ -648,7 +648,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     // buckets of similar list length (longest first) makes the 64 lists of a wave comparable.
     const bool use_grid = s_ctl[1] == 0;
     // diagnostics (nlos_ctx_last_path): this workgroup traces its rays through the in-kernel BVH query
-    if (!use_grid && a.retry && tid == 0) a.retry[blockIdx.x] = 0x200;
+    if (!use_grid && a.retry && tid == 0 && (TILED || pass > 0)) a.retry[blockIdx.x] = 0x200;   // (first pass, one workgroup per source: at the end)
 #ifdef NLOS_FWD_STAMPS
     if (TILED && tid == 0 && a.dbg && !use_grid && !ident) atomicAdd((unsigned long long*)&a.dbg[20], 1ull);   // entry overflow
     if (TILED && tid == 0 && a.dbg) atomicMax((unsigned long long*)&a.dbg[21], (unsigned long long)s_ctl[2]);
@@ -1029,7 +1029,12 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     FWD_STAMP();   // 5: sample + trace + histogram
     // diagnostics (nlos_ctx_debug_read what = 2): the coarsened resolution this workgroup ended up with; the
     // big-LDS launch only looks for the value 1
-    if (COARSE && a.retry && tid == 0) a.retry[blockIdx.x] = 0x100 + R;
+    // Every first-pass workgroup of the one-workgroup-per-source launch writes its code on its way out (0 = plain
+    // grid), so the array needs no memset before the launch.
+    if (a.retry && tid == 0) {
+        if (!TILED && pass == 0) a.retry[blockIdx.x] = COARSE ? 0x100 + R : (use_grid ? 0 : 0x200);
+        else if (COARSE) a.retry[blockIdx.x] = 0x100 + R;
+    }
     if (rows_in_lds && grow) {
         __syncthreads();
         if (!TILED) {
@@ -1109,7 +1114,6 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
     if (a.retry)
         note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forward_grid<FEAT, NCM, false, 1>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big), "hipFuncSetAttribute(k_forward_grid big-LDS)");
-    if (a.retry) note_hip(hipMemsetAsync(a.retry, 0, sizeof(int) * (size_t)a.src.L, stream), "hipMemsetAsync(retry)");
     note.backend = 1; note.reason = 0; note.grid_R = R; note.tiles = 1; note.tile_cap = 0;
     note.retry_workgroups = a.retry ? a.src.L : 0;
     // kScan slots of slack: the walk reads kScan entries per trip and may touch the slots after the last list

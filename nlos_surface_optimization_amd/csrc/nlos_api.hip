@@ -236,11 +236,22 @@ int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bo
     rc |= c->face_id.ensure(sizeof(int) * (size_t)nF);
     rc |= c->tri_zmin.ensure(sizeof(float) * (size_t)nF);
     if (rc) return NLOS_ERR_HIP;
-    // status[0] (bad face index) is sticky until the host has reported it; the rest is per-build scratch
+    // status[0] (bad face index) is sticky until the host has reported it; the rest is scratch its users initialise
     if (c->status_clear) { HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int), st)); c->status_clear = false; }
-    HIP_TRY(hipMemsetAsync(c->status.as<int>() + 1, 0, sizeof(int) * 63, st));
+#ifdef NLOS_BUILD_STAMPS
+    HIP_TRY(hipMemsetAsync(c->status.as<int>() + 1, 0, sizeof(int) * 63, st));      // (the chip-wide front end initialises its own words)
+#endif
+    // the build's status word follows it to pinned host memory; nobody waits for it here
+    if (!c->h_status) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_status), 64, hipHostMallocMapped));
+        c->h_status[0] = 0;
+        HIP_TRY(hipEventCreateWithFlags(&c->status_ev, hipEventDisableTiming));
+    }
+    int* h_status_dev = nullptr;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&h_status_dev), c->h_status, 0) != hipSuccess) { h_status_dev = nullptr; (void)hipGetLastError(); }
     nlos::BuildArgs b;
     b.vertices = V; b.faces = F; b.V = nV; b.F = nF;
+    b.host_status = h_status_dev;
     b.keys0 = c->keys0.as<uint32_t>(); b.keys1 = c->keys1.as<uint32_t>();
     b.idx0 = c->idx0.as<int>(); b.idx1 = c->idx1.as<int>();
     b.child = c->child.as<int>(); b.range = c->range.as<int>(); b.parent = c->parent.as<int>();
@@ -248,7 +259,7 @@ int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bo
     b.nodes = c->nodes.as<float4>(); b.tris = c->tris.as<float4>(); b.facerec = c->facerec.as<float4>();
     b.face_id = c->face_id.as<int>();
     b.tri_zmin = c->tri_zmin.as<float>();
-    nlos::launch_build_bvh(b, st);
+    const bool status_stored = nlos::launch_build_bvh(b, st);
     HIP_TRY(hipGetLastError());
 #ifdef NLOS_BUILD_STAMPS
     {   // diagnostic builds only: per-phase cycles of the build kernel
@@ -260,16 +271,10 @@ int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bo
 #endif
     c->built_F = nF; c->built_V = nV;
     c->mesh_gen = ++c->gen_counter;
-    // the build kernel's status word follows the build to pinned host memory; nobody waits for it here
-    if (!c->h_status) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_status), 64, hipHostMallocDefault));
-        c->h_status[0] = 0;
-        HIP_TRY(hipEventCreateWithFlags(&c->status_ev, hipEventDisableTiming));
-    }
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) { cs = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
     if (cs == hipStreamCaptureStatusNone) {     // (a captured render replays without the host looking on)
-        HIP_TRY(hipMemcpyAsync(c->h_status, c->status.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (!status_stored) HIP_TRY(hipMemcpyAsync(c->h_status, c->status.p, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(c->status_ev, st));
         c->status_pending = true;
     }

@@ -33,6 +33,7 @@ struct BuildArgs {
     int* arrive;             // [F-1]
     float* box;              // [6*(2F-1) + 8]
     int* status;             // [1] bit0: face index out of range
+    int* host_status;        // device-visible pinned host word (or null): the single-workgroup builder leaves status[0] there on its way out
     // outputs
     float4* nodes;           // [2*(2F-1)]  pre-order, 32 B per node
     float4* tris;            // [4*F]       64 B per triangle, Morton order
@@ -40,7 +41,8 @@ struct BuildArgs {
     int* face_id;            // [F]         original face index of sorted slot j
     float* tri_zmin;         // [F]         smallest vertex z of sorted triangle j
 };
-void launch_build_bvh(const BuildArgs& a, hipStream_t stream);
+// true: the kernel itself stored the status word to a.host_status (no copy needed behind the build)
+bool launch_build_bvh(const BuildArgs& a, hipStream_t stream);
 
 // ------------------------------------------------------------------ rendering
 struct SceneView {
