@@ -71,6 +71,10 @@ __device__ __forceinline__ void emit_node(const BuildArgs& a, int id, const floa
 }
 
 // Karras (2012) radix-tree node i over the sorted keys: children, covered leaf range, parent links
+// LEAN: only what the staged builder reads back (parent links, range starts).  (The three searches of the six nodes of
+// a thread run one after the other; running them in lock step -- their LDS probes issued together -- was tried and
+// is slower, 48 k -> 90 k cycles: the phase is bound by instruction issue at four waves per SIMD, not by latency.)
+template <bool LEAN = false>
 __device__ __forceinline__ void karras_node(const BuildArgs& a, const uint32_t* __restrict__ keys, int F, int i,
                                             int& left, int& right, int& last_out) {
     const int n_int = F - 1;
@@ -92,14 +96,16 @@ __device__ __forceinline__ void karras_node(const BuildArgs& a, const uint32_t* 
     int first = min(i, j), last = max(i, j);
     left = (first == gamma) ? (n_int + gamma) : gamma;
     right = (last == gamma + 1) ? (n_int + gamma + 1) : (gamma + 1);
-    a.child[2 * i] = left;
-    a.child[2 * i + 1] = right;
+    if (!LEAN) {
+        a.child[2 * i] = left;
+        a.child[2 * i + 1] = right;
+        a.range[2 * i + 1] = last;
+        a.arrive[i] = 0;
+    }
     a.range[2 * i] = first;
-    a.range[2 * i + 1] = last;
     last_out = last;
     a.parent[left] = i;
     a.parent[right] = i;
-    a.arrive[i] = 0;
 }
 
 // escape link of the node covering leaves [.., last]
@@ -569,7 +575,7 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, 
         nd_left[k] = nd_last[k] = 0;
         if (staged && i < n_int) {
             int left, right, last;
-            karras_node(a, tree_keys, F, i, left, right, last);
+            karras_node<true>(a, tree_keys, F, i, left, right, last);
             if (left < n_int) s_par[left] = (uint32_t)i;
             if (right < n_int) s_par[right] = (uint32_t)i;
             nd_left[k] = left;
