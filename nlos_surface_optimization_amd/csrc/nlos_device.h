@@ -25,12 +25,17 @@ __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y +
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// Numeric contract: a dot product is one multiplication and two fused multiply-adds, in this
+// order -- the oracle's dot3() is the same expression (fmaf), so both sides round identically; everything that is not
+// written as an explicit fma is a plain IEEE operation (-ffp-contract=off).  3 instructions instead of 5.
+__device__ __forceinline__ float dot(V3 a, V3 b) { return __fmaf_rn(a.z, b.z, __fmaf_rn(a.y, b.y, a.x * b.x)); }
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+// u a + v b + w c, per component u a first, then the two fused multiply-adds (oracle: bary3())
 __device__ __forceinline__ V3 bary(float u, V3 a, float v, V3 b, float w, V3 c) {
-    return ((a * u) + (b * v)) + (c * w);
+    return mk(__fmaf_rn(w, c.x, __fmaf_rn(v, b.x, u * a.x)), __fmaf_rn(w, c.y, __fmaf_rn(v, b.y, u * a.y)),
+              __fmaf_rn(w, c.z, __fmaf_rn(v, b.z, u * a.z)));
 }
 __device__ __forceinline__ V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
 

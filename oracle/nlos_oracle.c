@@ -42,13 +42,15 @@ static inline v3 add3(v3 a, v3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); 
 static inline v3 sub3(v3 a, v3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline v3 neg3(v3 a) { return mk(-a.x, -a.y, -a.z); }
 static inline v3 scl3(v3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-static inline float dot3(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+/* Numeric contract: one multiplication and two fused multiply-adds, in this order (the device's dot() is the same
+ * expression); everything not written as fmaf() is a plain IEEE operation (-ffp-contract=off). */
+static inline float dot3(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 static inline v3 cross3(v3 a, v3 b) {
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 /* u*a + v*b + w*c, the reference's "u * v1 + v * v2 + w * v3" */
 static inline v3 bary3(float u, v3 a, float v, v3 b, float w, v3 c) {
-    return add3(add3(scl3(a, u), scl3(b, v)), scl3(c, w));
+    return mk(fmaf(w, c.x, fmaf(v, b.x, u * a.x)), fmaf(w, c.y, fmaf(v, b.y, u * a.y)), fmaf(w, c.z, fmaf(v, b.z, u * a.z)));
 }
 static inline float comp(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
