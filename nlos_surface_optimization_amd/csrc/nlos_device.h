@@ -1,12 +1,12 @@
 // nlos_device.h -- device-side numeric contract of the gfx950 transient renderer.
 //
-// Everything that decides accept/reject of a surface sample is plain IEEE fp32
-// evaluated in a fixed order (this translation unit is built with
+// Everything that decides accept/reject of a surface sample is IEEE fp32
+// evaluated in a fixed order, exactly as written (this translation unit is built with
 // -ffp-contract=off; correctly rounded sqrt/div are hipcc defaults), so the HIP
 // kernels and the independent CPU oracle make bit-identical visibility decisions:
-//   dot(a,b)   = (a.x*b.x + a.y*b.y) + a.z*b.z
-//   cross(a,b) = (a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x)
-//   u*A+v*B+w*C = ((u*A) + (v*B)) + (w*C)
+//   dot(a,b)   = fma(a.z, b.z, fma(a.y, b.y, a.x*b.x))          (explicit fma on both sides)
+//   u*A+v*B+w*C = fma(w, C, fma(v, B, u*A)) per component         (explicit fma on both sides)
+//   cross(a,b) = (a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x)   (plain: exactly antisymmetric)
 // Reference behaviour restated here (paths relative to transient_rendering_cython/):
 //   sample map            smoothed_transient/transient_and_gradient.cpp:178-196
 //   float from random bits stratified_transient_raytracer/rng_sse.h:33-42

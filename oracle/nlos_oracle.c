@@ -4,11 +4,12 @@
  * against the original Embree binaries; pinned by tests/golden fixtures).
  *
  * Numeric contract (shared, by independent implementation, with the HIP path):
- *   - all per-sample math in IEEE fp32, no FMA contraction (-ffp-contract=off),
- *     correctly rounded sqrt/div; accumulation in fp64;
- *   - dot(a,b)   = (a.x*b.x + a.y*b.y) + a.z*b.z
- *   - cross(a,b) = (a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x)
- *   - a*v1 + b*v2 + c*v3 = ((a*v1) + (b*v2)) + (c*v3), per component
+ *   - all per-sample math in IEEE fp32, no contraction by the compiler (-ffp-contract=off),
+ *     correctly rounded sqrt/div; accumulation in fp64; two expressions are fused by definition,
+ *     written as explicit fmaf() here and __fmaf_rn() on the device:
+ *   - dot(a,b)   = fma(a.z, b.z, fma(a.y, b.y, a.x*b.x))
+ *   - a*v1 + b*v2 + c*v3 = fma(c, v3, fma(b, v2, a*v1)), per component
+ *   - cross(a,b) = (a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x)   (plain: exactly antisymmetric)
  *   - triangle test = Embree 3 Moeller-Trumbore (published algorithm,
  *     kernels/geometry/triangle_intersector_moeller.h), restated in tri_test();
  *     Embree's rcp()/rsqrt() Newton estimates are replaced by IEEE 1/x, 1/sqrt;
