@@ -138,14 +138,14 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                         GVec gv;
                         grad_vectors_nc<FEAT>(f, gc, on, onb, a.normal_term, a.sp.ggx_alpha, gv);
                         const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
-                        const V3 ce[3] = {cross(gv.t2, e0), cross(gv.t2, e1), cross(gv.t2, e2)};
+                        const V3 ce[3] = {cross_g(gv.t2, e0), cross_g(gv.t2, e1), cross_g(gv.t2, e2)};
                         double s0, s1;
                         grouped_taps(tt, s_diff, T, (double)(gc.d1 + gc.d2), lbd, resd, inv_res, s0, s1);
                         const V3 di = ((gc.dirA + gc.dirB) * 0.5f) * gv.inten_f;
                         const float bw[3] = {gc.u, gc.v, gc.w};
 #pragma unroll
                         for (int q = 0; q < 3; ++q) {
-                            V3 A1 = gv.t1 * bw[q] + ce[q];
+                            V3 A1 = grad_axpy(gv.t1, bw[q], ce[q]);
                             V3 A2 = di * bw[q];
                             acc[3 * q + 0] = fma((double)A1.x, s0, fma((double)A2.x, s1, acc[3 * q + 0]));
                             acc[3 * q + 1] = fma((double)A1.y, s0, fma((double)A2.y, s1, acc[3 * q + 1]));
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                     GVec gv;
                     grad_vectors<FEAT>(f, g, on, a.normal_term, a.v1_style, a.sp.ggx_alpha, gv);
                     const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
-                    const V3 ce0 = cross(gv.t2, e0), ce1 = cross(gv.t2, e1), ce2 = cross(gv.t2, e2);
+                    const V3 ce0 = cross_g(gv.t2, e0), ce1 = cross_g(gv.t2, e1), ce2 = cross_g(gv.t2, e2);
                     if (MODE == 3) {
                         // single-vertex per-bin gradient: output indexed by the tap's bin
                         V3 ce; float bw;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                     const V3 ce[3] = {ce0, ce1, ce2};
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
-                        V3 A1 = gv.t1 * bw[q] + ce[q];
+                        V3 A1 = grad_axpy(gv.t1, bw[q], ce[q]);
                         V3 A2 = di * bw[q];
                         acc[3 * q + 0] = fma((double)A1.x, s0, fma((double)A2.x, s1, acc[3 * q + 0]));
                         acc[3 * q + 1] = fma((double)A1.y, s0, fma((double)A2.y, s1, acc[3 * q + 1]));
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
                         twoh = (double)(2.0f * g.h);
                         jit_b0 = (int)floorf((2.0f * g.h - a.sp.lb) / a.sp.res) - a.two_rs;
                     }
-                    const V3 ce[3] = {cross(gv.t2, e0), cross(gv.t2, e1), cross(gv.t2, e2)};
+                    const V3 ce[3] = {cross_g(gv.t2, e0), cross_g(gv.t2, e1), cross_g(gv.t2, e2)};
                     double s0, s1;
                     if (JIT) {
                         // jitter/transient_and_gradient.cpp:944-969, as in k_gradient<FEAT, 4>
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
                     }
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
-                        const V3 A1 = gv.t1 * bw[q] + ce[q];
+                        const V3 A1 = grad_axpy(gv.t1, bw[q], ce[q]);
                         const V3 A2 = di * bw[q];
                         acc[3 * q + 0] = fma((double)A1.x, s0, fma((double)A2.x, s1, acc[3 * q + 0]));
                         acc[3 * q + 1] = fma((double)A1.y, s0, fma((double)A2.y, s1, acc[3 * q + 1]));

@@ -23,7 +23,7 @@ struct Face {
     V3 p0, p1, p2;
     int fid, i0, i1, i2;
     V3 fn;
-    float area;
+    float area, inv2a;       // inv2a = 1 / (2 area), the build's value
     bool degenerate;
 };
 
@@ -41,7 +41,8 @@ __device__ __forceinline__ Face load_face(const float4* __restrict__ rec, int j)
     V3 nr = cross(f.p1 - f.p0, f.p2 - f.p0);
     f.area = sqrtf(dot(nr, nr)) / 2.0f;
     f.degenerate = !(f.area > 0.0f);
-    f.fn = nr * (1.0f / (2.0f * f.area));
+    f.inv2a = 1.0f / (2.0f * f.area);
+    f.fn = nr * f.inv2a;
     return f;
 }
 
@@ -62,6 +63,7 @@ __device__ __forceinline__ void load_face_tri(const SceneView& sc, int j, Face& 
     tr.gmin = kGrazeRatio * td.z;
     f.area = td.z;
     f.degenerate = !(f.area > 0.0f);
+    f.inv2a = td.w;
     f.fn = tr.ng * td.w;
 }
 
@@ -172,6 +174,21 @@ __device__ __forceinline__ bool sample_geo_nc(const Face& f, const Tri& tr, V3 o
 // (smoothed_transient/transient_and_gradient.cpp:944-966, ggx/...:750-783).
 struct GVec { V3 t1, t2; float inten_f; };
 
+// Pass 2 decides nothing: the sample was accepted by pass 1 and its bins come from sample_geo()'s h, which stays the
+// contract's arithmetic.  The gradient vectors themselves may therefore use the 1-ulp reciprocal (v_rcp_f32) instead of
+// the correctly rounded division sequence (~10 instructions each) and fused multiply-adds: the result moves by ~1e-7
+// relative per sample, against a gradient tolerance of 1e-4 and the ~4e-7 the factored tap loop already differs by.
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ V3 cross_g(V3 a, V3 b) {              // pass-2 cross product: one rounding less per component
+    return mk(__fmaf_rn(a.y, b.z, -(a.z * b.y)), __fmaf_rn(a.z, b.x, -(a.x * b.z)), __fmaf_rn(a.x, b.y, -(a.y * b.x)));
+}
+__device__ __forceinline__ V3 grad_axpy(V3 a, float s, V3 b) {
+    return mk(__fmaf_rn(a.x, s, b.x), __fmaf_rn(a.y, s, b.y), __fmaf_rn(a.z, s, b.z));
+}
+__device__ __forceinline__ V3 fmadd(V3 a, float s, V3 b) {       // a * s + b
+    return mk(__fmaf_rn(a.x, s, b.x), __fmaf_rn(a.y, s, b.y), __fmaf_rn(a.z, s, b.z));
+}
+
 template <int FEAT>
 __device__ __forceinline__ void grad_vectors(const Face& f, const Geo& g, V3 on, int normal_term, int v1_style,
                                              float alpha, GVec& out) {
@@ -179,11 +196,13 @@ __device__ __forceinline__ void grad_vectors(const Face& f, const Geo& g, V3 on,
     float c3 = dot(g.n, -g.dir);
     if (c2 < 0) c2 = 0;
     if (c3 < 0) c3 = 0;
-    float ff = c2 * c3 / g.h / g.h;
-    float h2 = g.h * g.h, h4 = h2 * h2, h5 = h4 * g.h;
-    V3 inner = ((on * c3) - (g.n * c2)) + ((((-g.dir) * 4.0f) * c2) * c3);
+    const float h2 = g.h * g.h;
     V3 t1, gn = mk(0, 0, 0);
     if (FEAT & FEAT_GGX) {
+        // (the GGX branch keeps the contract's divisions: its factors are shared with the scalar alpha gradient)
+        const float ff = c2 * c3 / g.h / g.h;
+        const float h4 = h2 * h2, h5 = h4 * g.h;
+        const V3 inner = ((on * c3) - (g.n * c2)) + ((((-g.dir) * 4.0f) * c2) * c3);
         V3 wv = -g.dir;
         float nw = dot(g.n, wv);
         float brdf = ggx_eval(alpha, nw);
@@ -203,22 +222,19 @@ __device__ __forceinline__ void grad_vectors(const Face& f, const Geo& g, V3 on,
             gn = gn - g.n * ct;
         }
     } else {
+        const float ih2 = rcp_fast(h2);
+        const float ff = (c2 * c3) * ih2;
         out.inten_f = g.alb * ff * ff;
-        float sc = v1_style ? (2 * c2 * c3) : (2 * g.alb * c2 * c3);
-        t1 = inner * sc;
-        t1 = t1 * (1.0f / h5);
+        const float sc = (v1_style ? (2 * c2 * c3) : (2 * g.alb * c2 * c3)) * (ih2 * ih2) * rcp_fast(g.h);
+        t1 = fmadd(on, c3, fmadd(g.n, -c2, g.dir * (-4.0f * c2 * c3))) * sc;
         if (normal_term) {
-            float s0 = v1_style ? -2.0f : (-2 * g.alb);
-            gn = (((g.dir * s0) * c3) * c2) * c2;
-            gn = gn * (1.0f / h4);
-            float ct = dot(gn, g.n);
-            gn = gn - g.n * ct;
+            const float s0 = (v1_style ? -2.0f : (-2 * g.alb)) * c3 * c2 * c2 * (ih2 * ih2);
+            gn = g.dir * s0;
+            gn = fmadd(g.n, -dot(gn, g.n), gn);
         }
     }
-    V3 t2 = g.n * out.inten_f;
-    t2 = (t2 + gn) * (1.0f / (2 * f.area));
     out.t1 = t1;
-    out.t2 = t2;
+    out.t2 = fmadd(g.n, out.inten_f, gn) * f.inv2a;
 }
 
 // Row N: t1 = alb (ff_b grad ff_a + ff_a grad ff_b), grad ff = (n_o c3 - n c2 - 4 dir c2 c3) / d^3;
@@ -232,18 +248,18 @@ __device__ __forceinline__ void grad_vectors_nc(const Face& f, const GeoNC& g, V
     if (c3a < 0) c3a = 0;
     if (c2b < 0) c2b = 0;
     if (c3b < 0) c3b = 0;
-    const float ffa = c2a * c3a / g.d1 / g.d1, ffb = c2b * c3b / g.d2 / g.d2;
-    const V3 ia = ((na * c3a) - (g.n * c2a)) + ((((-g.dirA) * 4.0f) * c2a) * c3a);
-    const V3 ib = ((nb * c3b) - (g.n * c2b)) + ((((-g.dirB) * 4.0f) * c2b) * c3b);
-    const V3 ga = ia * (1.0f / ((g.d1 * g.d1) * g.d1));
-    const V3 gb = ib * (1.0f / ((g.d2 * g.d2) * g.d2));
+    const float i1 = rcp_fast(g.d1), i2 = rcp_fast(g.d2);            // (non-decision arithmetic, see rcp_fast)
+    const float ffa = c2a * c3a * (i1 * i1), ffb = c2b * c3b * (i2 * i2);
+    const V3 ia = fmadd(na, c3a, fmadd(g.n, -c2a, g.dirA * (-4.0f * c2a * c3a)));
+    const V3 ib = fmadd(nb, c3b, fmadd(g.n, -c2b, g.dirB * (-4.0f * c2b * c3b)));
+    const V3 ga = ia * ((i1 * i1) * i1);
+    const V3 gb = ib * ((i2 * i2) * i2);
     out.inten_f = g.alb * ffa * ffb;
-    out.t1 = ((ga * ffb) + (gb * ffa)) * g.alb;
+    out.t1 = fmadd(ga, ffb, gb * ffa) * g.alb;
     V3 gn = mk(0, 0, 0);
     if (normal_term) {
-        gn = (g.dirA * c3b) + (g.dirB * c3a);
-        gn = gn * (-(g.alb * c2a * c2b));
-        gn = gn * (1.0f / ((g.d1 * g.d1) * (g.d2 * g.d2)));
+        gn = fmadd(g.dirA, c3b, g.dirB * c3a);
+        gn = gn * (-(g.alb * c2a * c2b) * ((i1 * i1) * (i2 * i2)));
     }
     if (FEAT & FEAT_GGX) {
         // I = I_lambert * brdf(n, wa, wb), wx = -dirx:  dI/dp = brdf dI_l/dp + I_l (J_a^T ga + J_b^T gb) with
@@ -251,18 +267,14 @@ __device__ __forceinline__ void grad_vectors_nc(const Face& f, const GeoNC& g, V
         const V3 wa = -g.dirA, wb = -g.dirB;
         const GgxPair gp = ggx_pair<true>(alpha, g.n, wa, wb);
         const float il = out.inten_f;
-        const V3 pa = (gp.ga - wa * dot(wa, gp.ga)) * (-1.0f / g.d1);
-        const V3 pb = (gp.gb - wb * dot(wb, gp.gb)) * (-1.0f / g.d2);
+        const V3 pa = fmadd(wa, -dot(wa, gp.ga), gp.ga) * (-i1);
+        const V3 pb = fmadd(wb, -dot(wb, gp.gb), gp.gb) * (-i2);
         out.t1 = (out.t1 * gp.brdf) + ((pa + pb) * il);
         if (normal_term) gn = (gn * gp.brdf) + (gp.gn * il);
         out.inten_f = il * gp.brdf;
     }
-    if (normal_term) {
-        float ct = dot(gn, g.n);
-        gn = gn - g.n * ct;
-    }
-    V3 t2 = g.n * out.inten_f;
-    out.t2 = (t2 + gn) * (1.0f / (2 * f.area));
+    if (normal_term) gn = fmadd(g.n, -dot(gn, g.n), gn);
+    out.t2 = fmadd(g.n, out.inten_f, gn) * f.inv2a;
 }
 
 // bin of tap i: floor((2h + delta_i - lb) / res) in double
