@@ -138,7 +138,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                         GVec gv;
                         grad_vectors_nc<FEAT>(f, gc, on, onb, a.normal_term, a.sp.ggx_alpha, gv);
                         const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
-                        const V3 ce[3] = {cross_g(gv.t2, e0), cross_g(gv.t2, e1), cross_g(gv.t2, e2)};
+                        const V3 ce[3] = {cross(gv.t2, e0), cross(gv.t2, e1), cross(gv.t2, e2)};
                         double s0, s1;
                         grouped_taps(tt, s_diff, T, (double)(gc.d1 + gc.d2), lbd, resd, inv_res, s0, s1);
                         const V3 di = ((gc.dirA + gc.dirB) * 0.5f) * gv.inten_f;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                     GVec gv;
                     grad_vectors<FEAT>(f, g, on, a.normal_term, a.v1_style, a.sp.ggx_alpha, gv);
                     const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
-                    const V3 ce0 = cross_g(gv.t2, e0), ce1 = cross_g(gv.t2, e1), ce2 = cross_g(gv.t2, e2);
+                    const V3 ce0 = cross(gv.t2, e0), ce1 = cross(gv.t2, e1), ce2 = cross(gv.t2, e2);
                     if (MODE == 3) {
                         // single-vertex per-bin gradient: output indexed by the tap's bin
                         V3 ce; float bw;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
                         twoh = (double)(2.0f * g.h);
                         jit_b0 = (int)floorf((2.0f * g.h - a.sp.lb) / a.sp.res) - a.two_rs;
                     }
-                    const V3 ce[3] = {cross_g(gv.t2, e0), cross_g(gv.t2, e1), cross_g(gv.t2, e2)};
+                    const V3 ce[3] = {cross(gv.t2, e0), cross(gv.t2, e1), cross(gv.t2, e2)};
                     double s0, s1;
                     if (JIT) {
                         // jitter/transient_and_gradient.cpp:944-969, as in k_gradient<FEAT, 4>

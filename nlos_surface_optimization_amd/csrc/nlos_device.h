@@ -6,7 +6,7 @@
 // kernels and the independent CPU oracle make bit-identical visibility decisions:
 //   dot(a,b)   = fma(a.z, b.z, fma(a.y, b.y, a.x*b.x))          (explicit fma on both sides)
 //   u*A+v*B+w*C = fma(w, C, fma(v, B, u*A)) per component         (explicit fma on both sides)
-//   cross(a,b) = (a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x)   (plain: exactly antisymmetric)
+//   cross(a,b) = (fma(a.y, b.z, -(a.z*b.y)), fma(a.z, b.x, -(a.x*b.z)), fma(a.x, b.y, -(a.y*b.x)))   (explicit fma on both sides)
 // Reference behaviour restated here (paths relative to transient_rendering_cython/):
 //   sample map            smoothed_transient/transient_and_gradient.cpp:178-196
 //   float from random bits stratified_transient_raytracer/rng_sse.h:33-42
@@ -29,8 +29,11 @@ __device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y 
 // order -- the oracle's dot3() is the same expression (fmaf), so both sides round identically; everything that is not
 // written as an explicit fma is a plain IEEE operation (-ffp-contract=off).  3 instructions instead of 5.
 __device__ __forceinline__ float dot(V3 a, V3 b) { return __fmaf_rn(a.z, b.z, __fmaf_rn(a.y, b.y, a.x * b.x)); }
+// one multiplication and one fused multiply-add per component (oracle: cross3(), the same expression).  Not exactly
+// antisymmetric in its arguments: where two places must agree on a normal they evaluate the same call (make_tri below
+// and load_face() in render_common.h both form cross(p1 - p0, p2 - p0)).
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
-    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+    return mk(__fmaf_rn(a.y, b.z, -(a.z * b.y)), __fmaf_rn(a.z, b.x, -(a.x * b.z)), __fmaf_rn(a.x, b.y, -(a.y * b.x)));
 }
 // u a + v b + w c, per component u a first, then the two fused multiply-adds (oracle: bary3())
 __device__ __forceinline__ V3 bary(float u, V3 a, float v, V3 b, float w, V3 c) {
@@ -74,7 +77,7 @@ __device__ __forceinline__ Tri make_tri(V3 p0, V3 p1, V3 p2) {
     t.p0 = p0;
     t.e1 = p0 - p1;
     t.e2 = p2 - p0;
-    t.ng = cross(t.e2, t.e1);
+    t.ng = cross(-t.e1, t.e2);          // = cross(p1 - p0, p2 - p0) bit for bit (-e1 is p1 - p0 exactly)
     t.gmin = kGrazeRatio * (sqrtf(dot(t.ng, t.ng)) / 2.0f);
     return t;
 }

@@ -179,9 +179,6 @@ struct GVec { V3 t1, t2; float inten_f; };
 // the correctly rounded division sequence (~10 instructions each) and fused multiply-adds: the result moves by ~1e-7
 // relative per sample, against a gradient tolerance of 1e-4 and the ~4e-7 the factored tap loop already differs by.
 __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ V3 cross_g(V3 a, V3 b) {              // pass-2 cross product: one rounding less per component
-    return mk(__fmaf_rn(a.y, b.z, -(a.z * b.y)), __fmaf_rn(a.z, b.x, -(a.x * b.z)), __fmaf_rn(a.x, b.y, -(a.y * b.x)));
-}
 __device__ __forceinline__ V3 grad_axpy(V3 a, float s, V3 b) {
     return mk(__fmaf_rn(a.x, s, b.x), __fmaf_rn(a.y, s, b.y), __fmaf_rn(a.z, s, b.z));
 }

@@ -9,7 +9,7 @@
  *     written as explicit fmaf() here and __fmaf_rn() on the device:
  *   - dot(a,b)   = fma(a.z, b.z, fma(a.y, b.y, a.x*b.x))
  *   - a*v1 + b*v2 + c*v3 = fma(c, v3, fma(b, v2, a*v1)), per component
- *   - cross(a,b) = (a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x)   (plain: exactly antisymmetric)
+ *   - cross(a,b) = (fma(a.y, b.z, -(a.z*b.y)), fma(a.z, b.x, -(a.x*b.z)), fma(a.x, b.y, -(a.y*b.x)))
  *   - triangle test = Embree 3 Moeller-Trumbore (published algorithm,
  *     kernels/geometry/triangle_intersector_moeller.h), restated in tri_test();
  *     Embree's rcp()/rsqrt() Newton estimates are replaced by IEEE 1/x, 1/sqrt;
@@ -47,7 +47,7 @@ static inline v3 scl3(v3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
  * expression); everything not written as fmaf() is a plain IEEE operation (-ffp-contract=off). */
 static inline float dot3(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 static inline v3 cross3(v3 a, v3 b) {
-    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+    return mk(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
 /* u*a + v*b + w*c, the reference's "u * v1 + v * v2 + w * v3" */
 static inline v3 bary3(float u, v3 a, float v, v3 b, float w, v3 c) {
@@ -104,7 +104,7 @@ static inline tri_t make_tri(v3 p0, v3 p1, v3 p2) {
     t.p0 = p0;
     t.e1 = sub3(p0, p1);
     t.e2 = sub3(p2, p0);
-    t.ng = cross3(t.e2, t.e1);
+    t.ng = cross3(neg3(t.e1), t.e2);     /* = cross(p1 - p0, p2 - p0) bit for bit (-e1 is p1 - p0 exactly) */
     t.gmin = NLOS_GRAZE_RATIO * (sqrtf(dot3(t.ng, t.ng)) / 2.0f);
     return t;
 }
