@@ -1078,7 +1078,8 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
 #endif
     // finer cells shorten the per-sample walk for as long as the cell lists still fit: R = sqrt(F/2) always, and up to
     // sqrt(NLOS_GRID_RSCALE_MAX F) while a worst-case estimate of the entry count (each reachable face covering
-    // (1 + 1.38 R/sqrt F)^2 cells, 70 % of the faces reachable, 30 % margin; calibrated on where bunny_5k starts to overflow)
+    // (1 + 1.38 R/sqrt F)^2 cells -- the footprint calibrated on where bunny_5k starts to overflow --, every face reachable as on a
+    // height field seen from the wall, 30 % margin)
     // stays below the capacity that resolution leaves.  Measured at 1 055 faces: forward 2.08 -> 1.93 ms.
 #ifndef NLOS_GRID_RSCALE_MAX
 #define NLOS_GRID_RSCALE_MAX 1.6f
@@ -1100,7 +1101,7 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
             const size_t fx = fixed_bytes(r);
             if (fx >= kGridLdsBudget) continue;
             const float per_face = 1.f + 1.38f * (float)r / sf;
-            const float est = 1.3f * 0.7f * (float)a.sc.F * per_face * per_face;
+            const float est = 1.3f * (float)a.sc.F * per_face * per_face;
             if (est <= (float)((kGridLdsBudget - fx) / 4)) { R = r; break; }
         }
     }
