@@ -123,6 +123,17 @@ def test_last_path_reports_backend_reason_and_workgroup_outcomes(bunny, mannequi
     r.render_transient(to, tn, torch.from_numpy(vq).to(tv.device), torch.from_numpy(fq).to(tv.device), 256, 0.0, 2.0, 2.0 ** -5)
     p = r.last_path()
     assert p["backend"] == "bvh" and p["reason"] == "mesh below 64 faces"
+    # the grid resolution grows with the LDS a small mesh leaves free -- without sending a fully visible height field
+    # (every face reachable: the worst case of the entry estimate) into the coarsening path
+    n = 32
+    xs, ys = np.meshgrid(np.linspace(-0.3, 0.3, n), np.linspace(-0.3, 0.3, n))
+    vh = np.stack([xs.ravel(), ys.ravel(), 0.45 + 0.05 * np.sin(7 * xs.ravel()) * np.cos(5 * ys.ravel())], 1).astype(np.float32)
+    idx = np.arange(n * n).reshape(n, n)
+    qa, qb, qc, qd = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, 1:].ravel(), idx[1:, :-1].ravel()
+    fh = np.concatenate([np.stack([qa, qc, qb], 1), np.stack([qa, qd, qc], 1)]).astype(np.int32)
+    r.render_transient(to, tn, torch.from_numpy(vh).to(tv.device), torch.from_numpy(fh).to(tv.device), 4 * fh.shape[0], 0.3, 1.6, 2.0 ** -7)
+    p = r.last_path(count=True)
+    assert p["backend"] == "grid" and p["grid_R"] > int(round((fh.shape[0] / 2) ** 0.5)) and p["coarsened"] == 0 and p["big_lds"] == 0
     # large mesh -> tiled grid, face-major gradient
     v, f = bunny
     v2, f2 = mesh_io.subdivide(v, f, 1)
