@@ -18,10 +18,13 @@ as a child (one process per GPU over RCCL).  Started under torch.distributed.run
 differs from --gpus, or an RCCL group that did not come up with N ranks is an error (exit code != 0),
 never a silent one-GPU measurement.
 
-Rank 0 prints ONE JSON line.  Before any timing it runs the parity gate BASELINE.md section 3 promises:
-the CPU oracle renders a block of the workload's sources (the same block the `cpu_baseline` leg times),
+Rank 0 prints ONE JSON line.  Before any timing EVERY rank runs the parity gate BASELINE.md section 3 promises, on
+the workload that is timed (the metric's, or any of the side measurements: pairs, forward only, other meshes): the
+CPU oracle renders the first sources of the rank's block (at N = 1 the same block the `cpu_baseline` leg times),
 and rows and vertex gradient of a GPU render of that block must agree (transient rel-L2 <= 1e-5 and
-max-abs <= 1e-6 * max, gradient rel-L2 <= 1e-4); on failure nothing is timed and the exit code is 1.
+max-abs <= 1e-6 * max, gradient rel-L2 <= 1e-4); the ranks' verdicts are MIN-all-reduced; on failure nothing is
+timed and the exit code is 1.  At N = 1 the line also carries `strong_share`: the per-step time of every rank's
+block of the 2-, 4- and 8-way strong split, measured on this one GPU (`--as-rank K --of N` times a single block).
 `roofline` is measured live with HIP events on the launch stream (nlos_ctx_timing_mean); `cpu_baseline`
 times the CPU oracle (a port of the reference algorithm, kind "port") on rank 0 at N = 1 only.
 """
@@ -69,24 +72,37 @@ def load_pmc_summary():
 # ------------------------------------------------------------------------------------------------
 # CPU side of rank 0: the oracle as parity checker and as the reported baseline (never the product)
 # ------------------------------------------------------------------------------------------------
-def _oracle_block(v, f, origin, normal, lb, ub, res, num_sample, data_rows, n, threads):
-    """Rows and vertex gradient of the first n sources by the CPU oracle (total_sources = n); returns
-    (transient, gradient, seconds)."""
+def _oracle_block(v, f, origin, normal, lb, ub, res, num_sample, data_rows, n, threads, source_offset=0,
+                  forward_only=False, sensor=None, sensor_normal=None):
+    """Rows and vertex gradient of the first n sources of a block by the CPU oracle (total_sources = n; RNG keys
+    of the block's global source indices); returns (transient, gradient or None, seconds).  The same call for every
+    workload the bench can time: confocal forward + gradient, forward only, non-confocal pairs, any mesh."""
     import oracle
     oracle.build()
     o, nn = np.ascontiguousarray(origin[:n]), np.ascontiguousarray(normal[:n])
     d = np.ascontiguousarray(data_rows[:n])
     w = np.ones_like(d)
+    kw = dict(accel=1, threads=threads, seed=0, source_offset=int(source_offset))
     t0 = time.perf_counter()
-    tr, g, _ = oracle.render_gradient(o, nn, v, f, num_sample, lb, ub, res, d, w, refine=10, sigma_bin=1,
-                                      testing_flag=1, loss_flag=0, accel=1, threads=threads, seed=0)
+    if sensor is not None:
+        tr, g, _ = oracle.render_nonconfocal(o, nn, np.ascontiguousarray(sensor[:n]), np.ascontiguousarray(sensor_normal[:n]),
+                                             v, f, num_sample, lb, ub, res, data=None if forward_only else d,
+                                             weight=None if forward_only else w, refine=10, sigma_bin=1,
+                                             testing_flag=1, loss_flag=0, **kw)
+    elif forward_only:
+        tr, _ = oracle.render_transient(o, nn, v, f, num_sample, lb, ub, res, **kw)
+        g = None
+    else:
+        tr, g, _ = oracle.render_gradient(o, nn, v, f, num_sample, lb, ub, res, d, w, refine=10, sigma_bin=1,
+                                          testing_flag=1, loss_flag=0, **kw)
     return tr, g, time.perf_counter() - t0
 
 
-def cpu_reference(v, f, origin, normal, lb, ub, res, num_sample, data_rows, budget_s):
+def cpu_reference(v, f, origin, normal, lb, ub, res, num_sample, data_rows, budget_s, source_offset=0, share=1, **wk):
     """Oracle (CPU port of the reference algorithm, own BVH, per-thread buffers, literal 41-tap loop) on a bounded
-    sample of the same workload: the first `n` sources.  budget_s > 0: sized to about that much wall time and
-    reported as `cpu_baseline`; budget_s == 0: a small block for the parity gate only.
+    sample of the same workload: the first `n` sources of this rank's block.  budget_s > 0: sized to about that much
+    wall time and reported as `cpu_baseline`; budget_s == 0: a small block for the parity gate only (at most 48
+    sources and about 3 M rays; `share` ranks of one host run their gates at the same time and share its cores).
     Returns (n, transient rows, gradient, cpu_baseline dict or None)."""
     try:
         avail = len(os.sched_getaffinity(0))
@@ -97,11 +113,11 @@ def cpu_reference(v, f, origin, normal, lb, ub, res, num_sample, data_rows, budg
     L = origin.shape[0]
 
     def run(n, threads):
-        return _oracle_block(v, f, origin, normal, lb, ub, res, num_sample, data_rows, n, threads)
+        return _oracle_block(v, f, origin, normal, lb, ub, res, num_sample, data_rows, n, threads, source_offset, **wk)
 
     if budget_s <= 0:
-        n = min(48, L)
-        tr, g, _ = run(n, max(1, avail))
+        n = int(min(48, L, max(4, 3.0e6 // max(F * spt, 1))))
+        tr, g, _ = run(n, max(1, avail // max(share, 1)))
         return n, tr, g, None
     # pick the thread count that gives the best throughput on a short probe (SMT siblings and
     # container CPU quotas make "all logical CPUs" the wrong choice on some hosts)
@@ -128,23 +144,26 @@ def parity_gate(render_block, n, t_ref, g_ref):
     """the GPU render of the oracle's block must agree before anything is timed."""
     t_gpu, g_gpu = render_block(n)
     den_t = float(np.linalg.norm(t_ref))
-    den_g = float(np.linalg.norm(g_ref))
     out = {
         "rows": int(n),
         "transient_rel_l2": float(np.linalg.norm(t_gpu - t_ref) / den_t) if den_t > 0 else float("inf"),
         "transient_max_abs_over_max": float(np.abs(t_gpu - t_ref).max() / np.abs(t_ref).max()) if den_t > 0 else float("inf"),
-        "gradient_rel_l2": float(np.linalg.norm(g_gpu - g_ref) / den_g) if den_g > 0 else float("inf"),
         "tolerance": PARITY_TOL,
         "checker": "CPU oracle (oracle/nlos_oracle.c), same sample keys, block of the timed workload's first sources",
     }
-    out["pass"] = bool(all(out[k] <= PARITY_TOL[k] for k in PARITY_TOL))
+    if g_ref is not None:          # (forward-only workloads have no gradient to compare)
+        den_g = float(np.linalg.norm(g_ref))
+        out["gradient_rel_l2"] = float(np.linalg.norm(g_gpu - g_ref) / den_g) if den_g > 0 else float("inf")
+    out["pass"] = bool(all(out[k] <= PARITY_TOL[k] for k in PARITY_TOL if k in out))
     return out
 
 
 def workload_config(args, g, T, F, V, spt, L_total, world):
     """The `config` object of the JSON line (names the workload; the side-measurement flags say so)."""
     return {
-        "workload": ("NON-CONFOCAL pairs (row N side measurement, not the metric) " if args.non_confocal else "") +
+        "workload": ("ONE RANK'S SHARE (rank %d of %d) of the strong split, side measurement, not the metric: " % (args.as_rank, args.of)
+                     if args.of > 1 else "") +
+                    ("NON-CONFOCAL pairs (row N side measurement, not the metric) " if args.non_confocal else "") +
                     ("SUBDIVIDED mesh x4^%d (side measurement, not the metric) " % args.subdivide if args.subdivide else "") +
                     ("RE-DECIMATED mesh (side measurement, not the metric) " if args.faces else "") +
                     ("forward-only " if args.forward_only else "forward+gradient ") +
@@ -183,6 +202,13 @@ def parse_args(argv=None):
                     help="side measurement: exp_mannequin/cnlos_mannequin_threshold.obj (1055 faces) instead of the metric's bunny")
     ap.add_argument("--faces", type=int, default=0,
                     help="side measurement: subdivide once, then vertex-cluster down to about this many faces")
+    ap.add_argument("--as-rank", type=int, default=0,
+                    help="with --of N: side measurement on ONE GPU of what rank K of an N-rank strong split does per step "
+                         "(its block of the grid, global source offsets and 1/L scaling, no collective)")
+    ap.add_argument("--of", type=int, default=1, help="see --as-rank")
+    ap.add_argument("--share-steps", type=int, default=10,
+                    help="N = 1, metric workload: after the timed steps, time every rank's block of the 2-, 4- and 8-way strong "
+                         "split for this many steps each and report them as `strong_share` (0 = skip)")
     ap.add_argument("--non-confocal", action="store_true",
                     help="row N side measurement (not the metric): every source becomes a (laser, sensor) pair, "
                          "sensor = laser + (0.05, -0.03, 0)")
@@ -298,6 +324,10 @@ def run_rank(args, backend):
         origin_np, normal_np = grid_sources(g, g, 0.25)            # one 64x64 grid, split over the ranks
     L_total = origin_np.shape[0]
     lo, hi = ndist.shard_bounds(L_total, rank, world)
+    if args.of > 1:
+        if world != 1 or not (0 <= args.as_rank < args.of):
+            raise SystemExit("bench.py: --as-rank K --of N is a one-GPU side measurement (0 <= K < N, --gpus 1)")
+        lo, hi = ndist.shard_bounds(L_total, args.as_rank, args.of)
     L = hi - lo
 
     r = backend.make_renderer()
@@ -316,30 +346,43 @@ def run_rank(args, backend):
     if args.non_confocal:
         nc = {"sensor": (origin + torch.tensor([0.05, -0.03, 0.0], device=dev)).contiguous(), "sensor_normal": normal}
 
-    # ---- parity gate (rank 0's block of the very workload; the CPU leg doubles as the reported baseline) ----
-    plain = not (args.forward_only or args.non_confocal or args.subdivide or args.faces) and args.mesh == "bunny_5k"
+    # ---- parity gate: EVERY rank checks the first sources of ITS block of the very workload that is timed (confocal or
+    # pairs, forward-only or with the gradient, whatever the mesh); the flags are MIN-all-reduced, so a result line
+    # means every GPU passed.  On rank 0 at N = 1 the CPU leg doubles as the reported baseline. ----
+    plain = not (args.forward_only or args.non_confocal or args.subdivide or args.faces or args.of > 1) and args.mesh == "bunny_5k"
     parity, cpu_base = None, None
-    gate_ok = True
-    if rank == 0 and plain:
-        budget = 15.0 if (world == 1 and not args.no_cpu_baseline) else 0.0
-        data_np = data.cpu().numpy()
-        n_ref, t_ref, g_ref, cpu_base = cpu_reference(v_np, f_np, origin_np[lo:hi], normal_np[lo:hi], lb, ub, res,
-                                                      args.num_sample, data_np, budget)
+    budget = 15.0 if (world == 1 and plain and not args.no_cpu_baseline) else 0.0
+    data_np = data.cpu().numpy()
+    wk = {"forward_only": bool(args.forward_only)}
+    if args.non_confocal:
+        wk.update(sensor=nc["sensor"].cpu().numpy(), sensor_normal=nc["sensor_normal"].cpu().numpy())
+    n_ref, t_ref, g_ref, cpu_base = cpu_reference(v_np, f_np, origin_np[lo:hi], normal_np[lo:hi], lb, ub, res,
+                                                  args.num_sample, data_np, budget, source_offset=lo, share=world, **wk)
 
-        def render_block(n):
-            gb = torch.zeros((V, 3), dtype=torch.float64, device=dev)
-            tb, gb, _ = r.render_gradient(origin[:n].contiguous(), normal[:n].contiguous(), verts, faces,
-                                          args.num_sample, lb, ub, res, data=data[:n].contiguous(),
-                                          weight=weight[:n].contiguous(), refine_scale=10, sigma_bin=1,
-                                          testing_flag=1, loss_flag=0, gradient=gb, source_offset=lo, total_sources=n)
-            return tb.cpu().numpy(), gb.cpu().numpy()
+    def render_block(n):
+        ncb = {k: t[:n].contiguous() for k, t in nc.items()}
+        if args.forward_only:
+            tb, _ = r.render_transient(origin[:n].contiguous(), normal[:n].contiguous(), verts, faces, args.num_sample,
+                                       lb, ub, res, source_offset=lo, total_sources=n, **ncb)
+            return tb.cpu().numpy(), None
+        gb = torch.zeros((V, 3), dtype=torch.float64, device=dev)
+        tb, gb, _ = r.render_gradient(origin[:n].contiguous(), normal[:n].contiguous(), verts, faces,
+                                      args.num_sample, lb, ub, res, data=data[:n].contiguous(),
+                                      weight=weight[:n].contiguous(), refine_scale=10, sigma_bin=1,
+                                      testing_flag=1, loss_flag=0, gradient=gb, source_offset=lo, total_sources=n, **ncb)
+        return tb.cpu().numpy(), gb.cpu().numpy()
 
-        parity = parity_gate(render_block, n_ref, t_ref, g_ref)
-        gate_ok = parity["pass"]
+    parity = parity_gate(render_block, n_ref, t_ref, g_ref)
+    parity["rank"] = rank
+    gate_ok = parity["pass"]
     if world > 1:
         flag = torch.tensor([1.0 if gate_ok else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        gate_ok = bool(flag.item() > 0.5)
+        parity["all_ranks_pass"] = bool(flag.item() > 0.5)
+        parity["ranks_gated"] = world
+        if not gate_ok:
+            sys.stderr.write("bench.py: rank %d: PARITY GATE FAILED: %s\n" % (rank, json.dumps(parity)))
+        gate_ok = parity["all_ranks_pass"]
     diagnostic = bool(args.diagnostic_no_gate and not gate_ok)
     if not gate_ok and not diagnostic:
         if rank == 0:
@@ -373,11 +416,22 @@ def run_rank(args, backend):
         return time.perf_counter() - t0
 
     if args.prewarm_seconds > 0:
+        # step() holds a collective at N > 1, so every rank must run the SAME number of batches: the decision to go
+        # on is itself all-reduced (MAX of the elapsed time -- the loop ends for everybody once the slowest rank's
+        # clock says so); ranks that decided on their own clocks could leave the loop one batch apart and pair a
+        # leftover gradient all-reduce with the others' barrier
         t_pw = time.perf_counter()
-        while time.perf_counter() - t_pw < args.prewarm_seconds:
+        while True:
             for _ in range(8):
                 step()
             backend.sync()
+            el = time.perf_counter() - t_pw
+            if world > 1:
+                te_pw = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(te_pw, op=dist.ReduceOp.MAX)
+                el = float(te_pw.item())
+            if el >= args.prewarm_seconds:
+                break
     for _ in range(args.warmup):
         step()
     backend.sync()
@@ -409,6 +463,35 @@ def run_rank(args, backend):
             t_s = float(ts.item())
         sustained_ms = 1e3 * t_s / sustained_steps
 
+    # ---- strong scaling, the part one GPU can time: every rank's block of the 2-, 4- and 8-way split of this very grid
+    # (global source offsets, 1/L_total scaling, replicated scene build -- what a rank does per step, without the
+    # all-reduce) ----
+    share = None
+    if world == 1 and plain and args.share_steps > 0 and not diagnostic:
+        share = {}
+        for n_split in (2, 4, 8):
+            per = []
+            for k in range(n_split):
+                klo, khi = ndist.shard_bounds(L_total, k, n_split)
+                o_k, n_k = origin[klo:khi].contiguous(), normal[klo:khi].contiguous()
+                d_k, w_k = data[klo:khi].contiguous(), weight[klo:khi].contiguous()
+
+                def step_k():
+                    grad.zero_()
+                    r.render_gradient(o_k, n_k, verts, faces, args.num_sample, lb, ub, res, data=d_k, weight=w_k,
+                                      refine_scale=10, sigma_bin=1, testing_flag=1, loss_flag=0, gradient=grad,
+                                      source_offset=klo, total_sources=L_total)
+                for _ in range(3):
+                    step_k()
+                backend.sync()
+                t0 = time.perf_counter()
+                for _ in range(args.share_steps):
+                    step_k()
+                backend.sync()
+                per.append(1e3 * (time.perf_counter() - t0) / args.share_steps)
+            share[str(n_split)] = {"per_rank_ms": per, "max_ms": max(per),
+                                   "efficiency_without_collective": (1e3 * elapsed / args.steps) / (n_split * max(per))}
+
     if diagnostic:
         if rank == 0:
             sys.stderr.write("bench.py: DIAGNOSTIC run (parity gate failed, no result line): ms/step %.3f kernel_ms %s\n" % (
@@ -417,7 +500,7 @@ def run_rank(args, backend):
             dist.destroy_process_group()
         return 3
     if rank == 0:
-        samples_per_step = L_total * F * spt          # all ranks
+        samples_per_step = (L if args.of > 1 else L_total) * F * spt          # all ranks (--as-rank: this block only)
         ms = 1e3 * elapsed / args.steps
         cfg = workload_config(args, g, T, F, V, spt, L_total, world)
         if path is not None:
@@ -443,6 +526,15 @@ def run_rank(args, backend):
         }
         if parity is not None:
             out["parity"] = parity
+        if args.of > 1:
+            out["as_rank"] = {"rank": args.as_rank, "of": args.of, "sources": [lo, hi],
+                              "note": "one GPU timing what rank %d of a %d-rank strong split does per step (no collective); "
+                                      "`value` counts this block's samples only" % (args.as_rank, args.of)}
+        if share is not None:
+            share["note"] = ("measured on ONE GPU: every rank's block of the N-way strong split of this grid, %d steps each, "
+                             "scene build replicated, NO all-reduce (a 3V-double RCCL all-reduce per step comes on top); "
+                             "efficiency_without_collective = ms_per_step / (N x slowest block)" % args.share_steps)
+            out["strong_share"] = share
         # roofline of the dominant kernel, measured live (HIP events, rank 0, this rank's launches)
         names = ["bvh_build", "k_forward", "k_residual", "k_gradient"]
         dom = int(np.argmax(kt))

@@ -139,11 +139,13 @@ __device__ __forceinline__ void leaf_records_from(const BuildArgs& a, int j, int
     a.tris[kTriStride * j + 1] = make_float4(tr.e1.y, tr.e1.z, tr.e2.x, tr.e2.y);
     a.tris[kTriStride * j + 2] = make_float4(tr.e2.z, tr.ng.x, tr.ng.y, tr.ng.z);
     const float area = sqrtf(dot(tr.ng, tr.ng)) / 2.0f;
-    a.tris[kTriStride * j + 3] = make_float4(fminf(fminf(p0.z, p1.z), p2.z), __int_as_float(f), area, 1.0f / (2.0f * area));
+    const float inv2a = 1.0f / (2.0f * area);
+    a.tris[kTriStride * j + 3] = make_float4(fminf(fminf(p0.z, p1.z), p2.z), __int_as_float(f), area, inv2a);
     a.facerec[4 * j] = make_float4(p0.x, p0.y, p0.z, p1.x);
     a.facerec[4 * j + 1] = make_float4(p1.y, p1.z, p2.x, p2.y);
     a.facerec[4 * j + 2] = make_float4(p2.z, __int_as_float(f), __int_as_float(i0), __int_as_float(i1));
-    a.facerec[4 * j + 3] = make_float4(__int_as_float(i2), 0.0f, 0.0f, 0.0f);
+    // + the unit normal (load_face()'s fn): the grid build's grazing test reads it beside the vertices
+    a.facerec[4 * j + 3] = make_float4(__int_as_float(i2), tr.ng.x * inv2a, tr.ng.y * inv2a, tr.ng.z * inv2a);
     a.face_id[j] = f;
     a.tri_zmin[j] = fminf(fminf(p0.z, p1.z), p2.z);
     lb6[0] = fminf(fminf(p0.x, p1.x), p2.x) - pad;
@@ -171,11 +173,13 @@ __device__ __forceinline__ void leaf_records(const BuildArgs& a, const int* __re
     // per-face constants of the sample map, evaluated once per build with load_face()'s own expressions
     // (render_common.h; ng == cross(p1 - p0, p2 - p0) bit for bit): area and 1 / (2 area)
     const float area = sqrtf(dot(tr.ng, tr.ng)) / 2.0f;
-    a.tris[kTriStride * j + 3] = make_float4(fminf(fminf(p0.z, p1.z), p2.z), __int_as_float(f), area, 1.0f / (2.0f * area));
+    const float inv2a = 1.0f / (2.0f * area);
+    a.tris[kTriStride * j + 3] = make_float4(fminf(fminf(p0.z, p1.z), p2.z), __int_as_float(f), area, inv2a);
     a.facerec[4 * j] = make_float4(p0.x, p0.y, p0.z, p1.x);
     a.facerec[4 * j + 1] = make_float4(p1.y, p1.z, p2.x, p2.y);
     a.facerec[4 * j + 2] = make_float4(p2.z, __int_as_float(f), __int_as_float(i0), __int_as_float(i1));
-    a.facerec[4 * j + 3] = make_float4(__int_as_float(i2), 0.0f, 0.0f, 0.0f);
+    // + the unit normal (load_face()'s fn): the grid build's grazing test reads it beside the vertices
+    a.facerec[4 * j + 3] = make_float4(__int_as_float(i2), tr.ng.x * inv2a, tr.ng.y * inv2a, tr.ng.z * inv2a);
     a.face_id[j] = f;
     a.tri_zmin[j] = fminf(fminf(p0.z, p1.z), p2.z);
     lb6[0] = fminf(fminf(p0.x, p1.x), p2.x) - pad;
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256) void k_build_morton(BuildArgs a, const uint32_
         hi[c] = fkey_inv(bkeys[3 + c]);
         e = fmaxf(e, fmaxf(fabsf(lo[c]), fabsf(hi[c])));
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.box[6 * (size_t)(2 * a.F - 1)] = 1e-4f * e + 1e-30f;   // box padding
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.box[6 * (size_t)(2 * a.F - 1)] = 1.6e-3f * e + 1e-30f;   // box padding
     const float sx = hi[0] - lo[0], sy = hi[1] - lo[1], sz = hi[2] - lo[2];
     const float ix = sx > 0 ? 1.0f / sx : 0.0f, iy = sy > 0 ? 1.0f / sy : 0.0f, iz = sz > 0 ? 1.0f / sz : 0.0f;
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, 
             s_bounds[3 + c] = hi[c];
             e = fmaxf(e, fmaxf(fabsf(lo[c]), fabsf(hi[c])));
         }
-        s_bounds[6] = 1e-4f * e + 1e-30f;      // box padding >> fp32 rounding of hit points
+        s_bounds[6] = 1.6e-3f * e + 1e-30f;      // box padding >> fp32 rounding of hit points
     }
     __syncthreads();
     const float pad = s_bounds[6];

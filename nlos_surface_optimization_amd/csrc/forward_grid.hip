@@ -35,6 +35,7 @@ struct GridView {
     float z0, inv_qz;                 // quantised depth = floor((z - z0) * inv_qz), zmax levels over the scene
     int ib, zmax;                     // entry = depth (32 - 2 kSub - ib bits) | y mask | x mask | index (ib bits)
     int R;
+    float padx, pady;                 // sub-cell mask margin: kSubFrac + kSlopeAbs in sub-cells
 };
 
 __device__ __forceinline__ int cell_coord(float m, float g0, float inv_c, int R) {
@@ -66,6 +67,48 @@ __device__ __forceinline__ Proj2 project_tri(V3 o, V3 p0, V3 p1, V3 p2) {
 // both masks; a candidate survives iff  w <= rlim  (not entirely behind the hit),  (w & rmask) == rmask
 // (the slope point is inside the box) and it is not the ray's own face: three compares on one LDS word.
 struct BBoxF { float x0, x1, y0, y1; };
+// Conservative margins of the grid.  What they must cover is the error of a hit the exact test
+// reports, and that error grows like 1 / |cos| of the angle between ray and triangle normal: ~6 eps / |cos| of t along
+// the ray, ~3 eps |C| / |cos| beside it.  The BASE margins below are sized for |cos| >= 2^-6 (2.3e-5 t, 6e-6 m at
+// |C| ~ 0.5 m; they are round 2's, which passed 7 590 fuzz scenes under a rule that cut off there).  The grazing rule
+// of the contract now admits hits down to |cos| = NLOS_GRAZE_RATIO / 2 = 2^-10, sixteen times more error -- but only on
+// triangles that this source really sees that edge-on.  So every margin is scaled PER (source, triangle) by
+//     graze_scale = clamp(1 / (64 cos_min), 1, kGrazeMaxScale),   cos_min = dist(o, plane) / max_i |p_i - o|
+// (the smallest |cos| any ray from o can have where it meets the triangle's plane inside the triangle: n . (p - o) is
+// the same for every p of the plane).  98 % of the triangles keep the base margins; uniform margins of 8x / 16x cost
+// 12 % / 51 % of the kernel (measured, profiles/r03_ab_margins.log), the scaled ones nothing measurable.
+// Lateral margins are a fraction of a cell plus an absolute slope term (fine grids: the tiles of large meshes have
+// cells of 3e-3 slope units), depth margins a relative term plus one quantisation level.
+#ifndef NLOS_MARGIN_SCALE
+#define NLOS_MARGIN_SCALE 1.0f            // x the base margins (diagnostic builds: the A/B of uniform margins)
+#endif
+constexpr float kSlopeAbs = 5e-5f * NLOS_MARGIN_SCALE;                  // absolute lateral margin, slope units
+constexpr float kBoxFrac = 2e-3f * NLOS_MARGIN_SCALE;                   // bounding-box margin, cells
+constexpr float kEdgeFrac = 4e-3f * NLOS_MARGIN_SCALE;                  // edge-function slack, cells
+constexpr float kSubFrac = 0.02f * NLOS_MARGIN_SCALE;                   // sub-cell mask margin, sub-cells
+constexpr float kDepthEps = 1e-4f * NLOS_MARGIN_SCALE;                  // relative depth margin (x graze_scale)
+constexpr float kDepthRel = 1.0f + kDepthEps;                           // the ray's own depth level (arithmetic of zs only)
+constexpr float kGrazeMaxScale = 1.1f * (2.0f / (64.0f * NLOS_GRAZE_RATIO));   // 2^-6 / (ratio / 2), 10 % up
+
+// margin multiplier of triangle (p0, p1, p2) seen from o; nhat = its unit normal (facerec, the scene build's
+// ng / |ng|).  hmin = 1.1 / 64 x the distance from o to the farthest corner of the scene's box: a triangle whose plane
+// passes o at more than that cannot be seen at |cos| < 2^-6 -- one dot product and a compare for 98 % of the triangles.
+// Degenerate triangles (nhat = NaN) never report a hit; they get the maximum.
+__device__ __forceinline__ float graze_scale(V3 o, V3 p0, V3 p1, V3 p2, V3 nhat, float hmin) {
+#ifdef NLOS_DIAG_NO_GRAZE_SCALE   // diagnostic builds only (what the scaled margins cost): results can differ from the oracle's
+    return 1.0f;
+#endif
+    const V3 c0 = p0 - o;
+    const float h = fabsf(dot(nhat, c0));                                           // distance of o from the plane
+    float ms = 1.0f;
+    if (!(h >= hmin)) {
+        const V3 c1 = p1 - o, c2 = p2 - o;
+        const float d2 = fmaxf(fmaxf(dot(c0, c0), dot(c1, c1)), dot(c2, c2));
+        const float sc = sqrtf(d2) * __builtin_amdgcn_rcpf(h * (64.0f / 1.1f));     // 1.1 / (64 cos_min)
+        ms = fmaxf(fminf(sc, kGrazeMaxScale), 1.0f);                                // (NaN -> kGrazeMaxScale -> >= 1)
+    }
+    return ms;
+}
 #ifndef NLOS_KSUB
 #define NLOS_KSUB 4
 #endif
@@ -96,12 +139,13 @@ constexpr int kQueueWords = kQueueCap + 3;  // + a dump slot for the lanes that 
 constexpr int kGridNT = NLOS_GRID_NT;
 constexpr int kGridWaves = kGridNT / 64;
 
-__device__ __forceinline__ uint32_t make_entry(const GridView& g, const BBoxF& bb, int xx, int yy, uint32_t zq, int k) {
-    // the box is widened by 0.02 sub-cells: > 50x the fp32 error of the two projections (rcp, 1 ulp)
-    const float fx0 = ((bb.x0 - g.gx0) * g.inv_cw - (float)xx) * (float)kSub - 0.02f;
-    const float fx1 = ((bb.x1 - g.gx0) * g.inv_cw - (float)xx) * (float)kSub + 0.02f;
-    const float fy0 = ((bb.y0 - g.gy0) * g.inv_ch - (float)yy) * (float)kSub - 0.02f;
-    const float fy1 = ((bb.y1 - g.gy0) * g.inv_ch - (float)yy) * (float)kSub + 0.02f;
+__device__ __forceinline__ uint32_t make_entry(const GridView& g, const BBoxF& bb, int xx, int yy, uint32_t zq, int k, float ms) {
+    // the box is widened by ms x (kSubFrac sub-cells + kSlopeAbs) (g.padx, g.pady: in sub-cells; ms = graze_scale)
+    const float px = g.padx * ms, py = g.pady * ms;
+    const float fx0 = ((bb.x0 - g.gx0) * g.inv_cw - (float)xx) * (float)kSub - px;
+    const float fx1 = ((bb.x1 - g.gx0) * g.inv_cw - (float)xx) * (float)kSub + px;
+    const float fy0 = ((bb.y0 - g.gy0) * g.inv_ch - (float)yy) * (float)kSub - py;
+    const float fy1 = ((bb.y1 - g.gy0) * g.inv_ch - (float)yy) * (float)kSub + py;
     const int a0 = min(max((int)floorf(fx0), 0), kSub - 1), a1 = min(max((int)floorf(fx1), 0), kSub - 1);
     const int b0 = min(max((int)floorf(fy0), 0), kSub - 1), b1 = min(max((int)floorf(fy1), 0), kSub - 1);
     const uint32_t xm = (2u << a1) - (1u << a0), ym = (2u << b1) - (1u << b0);
@@ -117,12 +161,11 @@ __device__ __forceinline__ uint32_t make_entry(const GridView& g, const BBoxF& b
 // in every cell: 30 VALU operations per cell against 7 here, and the build phases were 41 % of the kernel.)
 struct RasterAll { __device__ __forceinline__ bool operator()(int, int, int, int) const { return true; } };
 template <class Fn, class Pre = RasterAll>
-__device__ __forceinline__ void raster_cells(float gx0, float gy0, float inv_cw, float inv_ch, int Rx, const Proj2& q, Fn fn,
+__device__ __forceinline__ void raster_cells(float gx0, float gy0, float inv_cw, float inv_ch, int Rx, const Proj2& q, float ms, Fn fn,
                                              Pre pre = Pre()) {
     const float cw = __builtin_amdgcn_rcpf(inv_cw), ch = __builtin_amdgcn_rcpf(inv_ch);
     // slack: the projection's rounding (1e-7) and, above all, the error of a reported hit under the grazing rule
-    // (<= ~1e-5 of the source-to-triangle distance laterally, i.e. < 1e-3 of a cell at the resolutions used)
-    const float mgx = 2e-3f * cw, mgy = 2e-3f * ch;
+    const float mgx = ms * (kBoxFrac * cw + kSlopeAbs), mgy = ms * (kBoxFrac * ch + kSlopeAbs);
     const int cx0 = cell_coord(fminf(fminf(q.ax, q.bx), q.cx) - mgx, gx0, inv_cw, Rx);
     const int cx1 = cell_coord(fmaxf(fmaxf(q.ax, q.bx), q.cx) + mgx, gx0, inv_cw, Rx);
     const int cy0 = cell_coord(fminf(fminf(q.ay, q.by), q.cy) - mgy, gy0, inv_ch, Rx);
@@ -135,9 +178,10 @@ __device__ __forceinline__ void raster_cells(float gx0, float gy0, float inv_cw,
     const float A0 = -(q.by - q.ay) * sgn, B0 = (q.bx - q.ax) * sgn, C0 = -(A0 * q.ax + B0 * q.ay);
     const float A1 = -(q.cy - q.by) * sgn, B1 = (q.cx - q.bx) * sgn, C1 = -(A1 * q.bx + B1 * q.by);
     const float A2 = -(q.ay - q.cy) * sgn, B2 = (q.ax - q.cx) * sgn, C2 = -(A2 * q.cx + B2 * q.cy);
-    const float t0 = 4e-3f * (fabsf(A0) * cw + fabsf(B0) * ch);
-    const float t1 = 4e-3f * (fabsf(A1) * cw + fabsf(B1) * ch);
-    const float t2 = 4e-3f * (fabsf(A2) * cw + fabsf(B2) * ch);
+    const float ecw = ms * (kEdgeFrac * cw + kSlopeAbs), ech = ms * (kEdgeFrac * ch + kSlopeAbs);
+    const float t0 = fabsf(A0) * ecw + fabsf(B0) * ech;
+    const float t1 = fabsf(A1) * ecw + fabsf(B1) * ech;
+    const float t2 = fabsf(A2) * ecw + fabsf(B2) * ech;
     // value at the first cell's inside-most corner (+ slack), and the steps per cell
     const float x00 = gx0 + (float)cx0 * cw, y00 = gy0 + (float)cy0 * ch;
     float E0 = A0 * (x00 + (A0 > 0 ? cw : 0.0f)) + B0 * (y00 + (B0 > 0 ? ch : 0.0f)) + (C0 + t0);
@@ -155,26 +199,28 @@ __device__ __forceinline__ void raster_cells(float gx0, float gy0, float inv_cw,
     }
 }
 // first cell of the bounding box as raster_cells() derives it (same expressions, same bits)
-__device__ __forceinline__ void raster_origin(const GridView& g, const Proj2& q, int& cx0, int& cy0) {
+__device__ __forceinline__ void raster_origin(const GridView& g, const Proj2& q, float ms, int& cx0, int& cy0) {
     const float cw = __builtin_amdgcn_rcpf(g.inv_cw), ch = __builtin_amdgcn_rcpf(g.inv_ch);
-    const float mgx = 2e-3f * cw, mgy = 2e-3f * ch;
+    const float mgx = ms * (kBoxFrac * cw + kSlopeAbs), mgy = ms * (kBoxFrac * ch + kSlopeAbs);
     cx0 = cell_coord(fminf(fminf(q.ax, q.bx), q.cx) - mgx, g.gx0, g.inv_cw, g.R);
     cy0 = cell_coord(fminf(fminf(q.ay, q.by), q.cy) - mgy, g.gy0, g.inv_ch, g.R);
 }
 template <class Fn, class Pre = RasterAll>
-__device__ __forceinline__ void raster_tri(const GridView& g, const Proj2& q, Fn fn, Pre pre = Pre()) {
-    raster_cells(g.gx0, g.gy0, g.inv_cw, g.inv_ch, g.R, q, fn, pre);
+__device__ __forceinline__ void raster_tri(const GridView& g, const Proj2& q, float ms, Fn fn, Pre pre = Pre()) {
+    raster_cells(g.gx0, g.gy0, g.inv_cw, g.inv_ch, g.R, q, ms, fn, pre);
 }
 // the same on the coarse map of the depth bounds (one cell = 2 x 2 cells of the grid, R2 = (R + 1) / 2 per side): a
 // coarse cell is touched iff one of its four cells is (up to the slack), at a quarter of the cells
 template <class Fn>
 __device__ __forceinline__ void raster_tri_coarse(const GridView& g, int R2, const Proj2& q, Fn fn) {
-    raster_cells(g.gx0, g.gy0, 0.5f * g.inv_cw, 0.5f * g.inv_ch, R2, q, fn);
+    // (the rays towards a LIVE face end inside its projection up to rounding: base margins; what scales with the
+    // face's grazing angle is the depth its own hits are reported at, see zb at the call sites)
+    raster_cells(g.gx0, g.gy0, 0.5f * g.inv_cw, 0.5f * g.inv_ch, R2, q, 1.0f, fn);
 }
 
 // Slope-space frame of a source: bounding rectangle of the projection of the BVH's (padded) root box.
 // Shared by the grid kernel and the tile-binning kernel, which must agree bit for bit.
-struct SourceFrame { bool ok; float gx0, gy0, wx, wy, zr0, zr1; };
+struct SourceFrame { bool ok; float gx0, gy0, wx, wy, zr0, zr1, hmin; };
 __device__ __forceinline__ SourceFrame source_frame(const float4* __restrict__ nodes, V3 o) {
     SourceFrame fr;
     const float4 ra = nodes[0], rb = nodes[1];
@@ -190,6 +236,9 @@ __device__ __forceinline__ SourceFrame source_frame(const float4* __restrict__ n
     fr.wy = fmaxf(gy1 - gy0, 1e-12f);
     fr.gx0 = gx0 - 1e-3f * fr.wx;
     fr.gy0 = gy0 - 1e-3f * fr.wy;
+    // graze_scale(): plane distance below which a triangle of this scene can be seen at |cos| < 2^-6 (x 1.1)
+    const float fx = fmaxf(fabsf(xl), fabsf(xh)), fy = fmaxf(fabsf(yl), fabsf(yh)), fz = fmaxf(fabsf(fr.zr0), fabsf(fr.zr1));
+    fr.hmin = sqrtf(fx * fx + fy * fy + fz * fz) * (1.1f / 64.0f);
     return fr;
 }
 
@@ -204,7 +253,7 @@ __global__ __launch_bounds__(512) void k_tile_bin(ForwardArgs a, int R, int from
     const int ntx = a.tiles_x, nty = a.tiles_y;
     const float tw = fr.wx * 1.002f / (float)ntx, th = fr.wy * 1.002f / (float)nty;
     const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
-    const float mx = 4e-3f * tw / (float)R, my = 4e-3f * th / (float)R;
+    const float mx0 = kEdgeFrac * tw / (float)R + kSlopeAbs, my0 = kEdgeFrac * th / (float)R + kSlopeAbs;
     // slot allocation with LDS counters (one workgroup owns the whole source): global atomics on the few
     // per-tile counters were the bottleneck (2.5 ms for 1024 sources x 20 k faces)
     __shared__ int s_cnt[1024];
@@ -215,6 +264,9 @@ __global__ __launch_bounds__(512) void k_tile_bin(ForwardArgs a, int R, int from
     for (int j = threadIdx.x; j < a.sc.F; j += blockDim.x) {
         const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
         const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
+        const float4 q3 = a.sc.facerec[4 * j + 3];
+        const float ms = graze_scale(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), mk(q3.y, q3.z, q3.w), fr.hmin);
+        const float mx = ms * mx0, my = ms * my0;
         const float bx0 = fminf(fminf(q.ax, q.bx), q.cx) - mx, bx1 = fmaxf(fmaxf(q.ax, q.bx), q.cx) + mx;
         const float by0 = fminf(fminf(q.ay, q.by), q.cy) - my, by1 = fmaxf(fmaxf(q.ay, q.by), q.cy) + my;
         // one extra tile on each side covers the rounding of the tile origins (gx0 + t * tw)
@@ -340,6 +392,8 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             g.inv_cw = (float)R / tw;
             g.inv_ch = (float)R / th;
         }
+        g.padx = kSubFrac + kSlopeAbs * (float)kSub * g.inv_cw;
+        g.pady = kSubFrac + kSlopeAbs * (float)kSub * g.inv_ch;
         g.ib = IB;
         g.zmax = (1 << (32 - 2 * kSub - IB)) - 1;
         g.z0 = zr0;
@@ -356,6 +410,8 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             g.inv_cw = (float)Rn / (fr.wx * 1.002f);
             g.inv_ch = (float)Rn / (fr.wy * 1.002f);
         }
+        g.padx = kSubFrac + kSlopeAbs * (float)kSub * g.inv_cw;
+        g.pady = kSubFrac + kSlopeAbs * (float)kSub * g.inv_ch;
     };
 
     if (COARSE) set_grid_res(max(8, (R * 3) >> 2));      // the lists overflowed at R_launch: start one step coarser
@@ -439,6 +495,10 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             load_face_tri<FEAT>(a.sc, jg, f, tr_unused);
             const bool dark = face_dark(f);
             live = !dark;
+            // does this source see the face at |cos| < 2^-6 somewhere (graze_scale() > 1)?  One compare on the plane
+            // distance face_dark() has just formed; the counting pass reads the flag instead of testing every triangle again
+            const bool grazing = !(fabsf(dot(f.fn, o - f.p0)) >= fr.hmin);
+            if (frame_ok && !(TILED && ident)) g_cov[j] = grazing ? (uint16_t)1 : (uint16_t)0;
 #ifdef NLOS_DIAG_NO_DARKZERO       // diagnostic builds only
             if (false) {
 #else
@@ -453,8 +513,11 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
 #else
             if (live && frame_ok && !(TILED && ident)) {
 #endif
+                // the largest depth at which an own hit of this face can be REPORTED: its farthest vertex, plus the error
+                // of t at the face's grazing angle
                 const float zfar = fmaxf(fmaxf(f.p0.z, f.p1.z), f.p2.z) - o.z;
-                const uint32_t zb = __float_as_uint(fmaxf(zfar, 0.0f) * 1.0001f + 1e-30f);
+                const float msf = grazing ? graze_scale(o, f.p0, f.p1, f.p2, f.fn, fr.hmin) : 1.0f;
+                const uint32_t zb = __float_as_uint(fmaxf(zfar, 0.0f) * (1.0f + kDepthEps * msf) + 1e-30f);
                 const Proj2 q = project_tri(o, f.p0, f.p1, f.p2);
                 raster_tri_coarse(g, R2, q, [&](int cx, int cy) { atomicMax(&s_zc[cy * R2 + cx], zb); });
             }
@@ -496,7 +559,9 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     const int jg = gid(j);
                     const float4 q0 = a.sc.facerec[4 * jg], q1 = a.sc.facerec[4 * jg + 1], q2 = a.sc.facerec[4 * jg + 2];
                     const float zfar = fmaxf(fmaxf(q0.z, q1.y), q2.x) - o.z;
-                    const uint32_t zb = __float_as_uint(fmaxf(zfar, 0.0f) * 1.0001f + 1e-30f);
+                    const float4 q3 = a.sc.facerec[4 * jg + 3];
+                    const float msf = graze_scale(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), mk(q3.y, q3.z, q3.w), fr.hmin);
+                    const uint32_t zb = __float_as_uint(fmaxf(zfar, 0.0f) * (1.0f + kDepthEps * msf) + 1e-30f);
                     const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
                     raster_tri_coarse(g, R2, q, [&](int cx, int cy) { atomicMax(&s_zc[cy * R2 + cx], zb); });
                 }
@@ -515,23 +580,33 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 const int j = gid(jl);
                 const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
                 if (pend_jl >= 0) g_cov[pend_jl] = pend_cov;       // the previous triangle's cells, behind this one's loads (see the trace)
+                // margins of this triangle as an occluder: x 1 unless the source sees it at less than 0.9 degrees (flagged by
+                // the setup pass; after a coarsening restart the flags are gone -- the coverage words took their place --
+                // and every triangle is tested)
+                float ms = 1.0f;
+                if (attempt > 0 || g_cov[jl] != 0) {
+                    const float4 q3 = a.sc.facerec[4 * j + 3];
+                    ms = graze_scale(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), mk(q3.y, q3.z, q3.w), fr.hmin);
+                }
                 const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
-                const uint32_t zn = __float_as_uint(fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f));
+                // smallest depth at which a hit on it can be REPORTED (its nearest vertex, minus the error of t)
+                const uint32_t zn = __float_as_uint(fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f) * (1.0f - kDepthEps * ms));
                 // the cells the triangle enters are remembered for the fill pass (16 bits per triangle in global
                 // scratch): a bit per cell of a bounding box of up to 4 x 4 cells, relative to its first cell (which
-                // the fill pass re-derives from the projection); 0xFFFF = rasterise again (larger boxes, and the
-                // rare box that is entered in all sixteen cells)
+                // the fill pass re-derives from the projection); 0xFFFF = rasterise again (larger boxes, the
+                // rare box that is entered in all sixteen cells, and every triangle with scaled margins: the fill pass
+                // then knows that a replayed mask means ms == 1)
                 int bx0 = 0, by0 = 0;
                 bool big = false, reach = false;
                 uint32_t cv = 0u;
-                raster_tri(g, q, [&](int xx, int yy) {
+                raster_tri(g, q, ms, [&](int xx, int yy) {
                     if (zn <= s_zc[(yy >> 1) * R2 + (xx >> 1)]) {
                         atomicAdd(&s_cell[yy * R + xx], 1u);
                         cv |= 1u << ((((yy - by0) & 3) << 2) + ((xx - bx0) & 3));
                     }
                 }, [&](int cx0, int cx1, int cy0, int cy1) -> bool {
                     bx0 = cx0; by0 = cy0;
-                    big = cx1 - cx0 > 3 || cy1 - cy0 > 3;
+                    big = cx1 - cx0 > 3 || cy1 - cy0 > 3 || ms > 1.0f;
                     reach = reachable(zn)(cx0, cx1, cy0, cy1);
                     return reach;
                 });
@@ -604,30 +679,36 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 const int j = gid(jl);
                 const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
                 const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
-                const float zmin_rel = fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f);
+                // a replayed coverage mask means base margins (the counting pass sends every scaled triangle here as 0xFFFF)
+                float ms = 1.0f;
+                if (cov == 0xFFFFu) {
+                    const float4 q3 = a.sc.facerec[4 * j + 3];
+                    ms = graze_scale(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), mk(q3.y, q3.z, q3.w), fr.hmin);
+                }
+                const float zmin_rel = fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f) * (1.0f - kDepthEps * ms);
                 const uint32_t zn = __float_as_uint(zmin_rel);
                 const uint32_t zq = (uint32_t)min(max((int)floorf((zmin_rel - g.z0) * g.inv_qz) - 1, 0), g.zmax);
                 BBoxF bb;
                 bb.x0 = fminf(fminf(q.ax, q.bx), q.cx); bb.x1 = fmaxf(fmaxf(q.ax, q.bx), q.cx);
                 bb.y0 = fminf(fminf(q.ay, q.by), q.cy); bb.y1 = fmaxf(fmaxf(q.ay, q.by), q.cy);
                 if (cov == 0xFFFFu) {
-                    raster_tri(g, q, [&](int xx, int yy) {
+                    raster_tri(g, q, ms, [&](int xx, int yy) {
                         if (zn <= s_zc[(yy >> 1) * R2 + (xx >> 1)]) {
                             const int c = yy * R + xx;
                             uint32_t pos = atomicAdd(&s_cell[c], 1u);
-                            s_ent[pos] = make_entry(g, bb, xx, yy, zq, jl);
+                            s_ent[pos] = make_entry(g, bb, xx, yy, zq, jl, ms);
                             if (len_ok) nmax = max(nmax, (uint32_t)s_len8[c]);
                         }
                     }, reachable(zn));
                 } else {
                     int bx0, by0;
-                    raster_origin(g, q, bx0, by0);
+                    raster_origin(g, q, 1.0f, bx0, by0);
                     for (uint32_t m = cov; m; m &= m - 1u) {
                         const int bit = __ffs((int)m) - 1;
                         const int xx = bx0 + (bit & 3), yy = by0 + (bit >> 2);
                         const int c = yy * R + xx;
                         uint32_t pos = atomicAdd(&s_cell[c], 1u);
-                        s_ent[pos] = make_entry(g, bb, xx, yy, zq, jl);
+                        s_ent[pos] = make_entry(g, bb, xx, yy, zq, jl, 1.0f);
                         if (len_ok) nmax = max(nmax, (uint32_t)s_len8[c]);
                     }
                 }
@@ -787,9 +868,9 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             if (TILED && !compact && has_ray && frame_ok) {
                 // overflowed subset: every face is visited, most of them lie outside this tile
                 const Proj2 q = project_tri(o, f.p0, f.p1, f.p2);
-                const float cwm = __builtin_amdgcn_rcpf(g.inv_cw) * (1.0f + 4e-3f), chm = __builtin_amdgcn_rcpf(g.inv_ch) * (1.0f + 4e-3f);
-                has_ray = fmaxf(fmaxf(q.ax, q.bx), q.cx) >= g.gx0 - 4e-3f * cwm && fminf(fminf(q.ax, q.bx), q.cx) <= g.gx0 + (float)R * cwm &&
-                          fmaxf(fmaxf(q.ay, q.by), q.cy) >= g.gy0 - 4e-3f * chm && fminf(fminf(q.ay, q.by), q.cy) <= g.gy0 + (float)R * chm;
+                const float cwm = __builtin_amdgcn_rcpf(g.inv_cw) * (1.0f + kEdgeFrac), chm = __builtin_amdgcn_rcpf(g.inv_ch) * (1.0f + kEdgeFrac);
+                has_ray = fmaxf(fmaxf(q.ax, q.bx), q.cx) >= g.gx0 - kEdgeFrac * cwm - kSlopeAbs && fminf(fminf(q.ax, q.bx), q.cx) <= g.gx0 + (float)R * cwm + kSlopeAbs &&
+                          fmaxf(fmaxf(q.ay, q.by), q.cy) >= g.gy0 - kEdgeFrac * chm - kSlopeAbs && fminf(fminf(q.ay, q.by), q.cy) <= g.gy0 + (float)R * chm + kSlopeAbs;
             }
             const uint64_t key = (kbase0 + (uint64_t)f.fid) * (uint64_t)spt + (uint64_t)s;
             V3 dir = mk(0.0f, 0.0f, 1.0f);
@@ -866,7 +947,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     rmask = (1u << (IB + sx)) | (1u << (IB + kSub + sy));
                     // depth level of the own-face hit, rounded up: anything quantised deeper cannot occlude
                     const float zs = t_self * dir.z;
-                    const uint32_t rq = (uint32_t)min(max((int)floorf((zs * 1.0001f - g.z0) * g.inv_qz) + 1, 0), g.zmax);
+                    const uint32_t rq = (uint32_t)min(max((int)floorf((zs * kDepthRel - g.z0) * g.inv_qz) + 1, 0), g.zmax);
                     rlim = (rq << (IB + 2 * kSub)) | ((1u << (IB + 2 * kSub)) - 1u);
                     const int c = cyy * R + cxx;
                     e1 = s_cell[c];

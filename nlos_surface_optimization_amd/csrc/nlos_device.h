@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/nlos_contract.h"
+
 namespace nlos {
 
 struct V3 { float x, y, z; };
@@ -62,13 +64,13 @@ __device__ __forceinline__ void sample_st(uint64_t seed, uint64_t k, float& S, f
 // ------------------------------------------------------------ triangle record
 // 64-byte record (one cache-line half, 4 x dwordx4), sorted (Morton) order:
 //   p0, e1 = p0-p1, e2 = p2-p0, ng = e2 x e1, zmin (smallest vertex z), original face id
-// Grazing rule (numeric contract): a ray that meets a
-// triangle's plane at less than asin(2^-6) = 0.9 degrees does not hit it: |ng . d| >= gmin = |ng| / 64 =
-// kGrazeRatio * area is part of the hit test, for the sampled face and for occluders alike.  Below that angle
-// t = T / den is only as good as den and the reported hit can lie millimetres off the ray, where no culled query
-// can follow it; above it every back-end (perspective grid, tiled grid, BVH packets, stackless BVH) enumerates
-// exactly the hits of the all-faces definition.
-constexpr float kGrazeRatio = 0.03125f;
+// Grazing rule (numeric contract, DESIGN.md section 2, include/nlos_contract.h): a ray that meets a
+// triangle's plane at less than asin(2^-10) = 0.056 degrees does not hit it: |ng . d| >= gmin = |ng| / 1024 =
+// kGrazeRatio * area (for a unit direction; row E scales the bound by |d|) is part of the hit test, for the sampled
+// face and for occluders alike.  Below that angle t = T / den is only as good as den and the reported hit can lie
+// millimetres off the ray, where no culled query can follow it; above it every back-end (perspective grid, tiled
+// grid, BVH packets, stackless BVH) enumerates exactly the hits of the all-faces definition.
+constexpr float kGrazeRatio = NLOS_GRAZE_RATIO;
 struct Tri { V3 p0, e1, e2, ng; float gmin; };
 constexpr int kTriStride = 4;   // float4 per record: p0, e1, e2, ng | zmin, face id, area, 1 / (2 area)
 
@@ -192,12 +194,11 @@ __device__ __forceinline__ bool box_test(float4 a, float4 b, const RayBox& r, fl
     float t0z = (a.z - r.oz) * r.iz, t1z = (b.y - r.oz) * r.iz;
     float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
     float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-    // widen the interval: boxes are padded at build time, this covers the slab arithmetic and -- partly --
-    // the error of t itself for triangles the ray meets at a grazing angle (t = T / den with den -> 0 is only
-    // as good as den; a box test that prunes by t can then disagree with the brute-force definition of the
-    // closest hit, see DESIGN.md section 2 "grazing occluders")
+    // widen the interval: boxes are padded at build time, this covers the slab arithmetic and the error of t itself
+    // for triangles the ray meets at a grazing angle (t = T / den is only as good as den: <= ~4e-4 t at the 2^-10
+    // cosine the grazing rule admits)
 #ifndef NLOS_BOX_EPS
-#define NLOS_BOX_EPS 1e-4f
+#define NLOS_BOX_EPS 1.6e-3f
 #endif
     tn = tn - fabsf(tn) * NLOS_BOX_EPS;
     tf = tf + fabsf(tf) * NLOS_BOX_EPS;
@@ -247,6 +248,10 @@ __device__ __forceinline__ int closest_hit(const float4* __restrict__ nodes, int
     rb.ix = safe_inv(d.x); rb.iy = safe_inv(d.y); rb.iz = safe_inv(d.z);
     int best = -1, best_fid = 0x7fffffff;
     bt = __int_as_float(0x7f800000);
+    // row E takes the caller's direction as it is (embree_intersector/c_embree_intersector.cpp:20-45 hands it to Embree
+    // unnormalised): |ng . d| scales with |d|, so the grazing bound does too -- the cut-off angle must not depend on
+    // the direction's length
+    const float dl = sqrtf(dot(d, d));
     int i = 0;
     while (i >= 0) {
         float4 a = nodes[2 * i], b = nodes[2 * i + 1];
@@ -256,6 +261,7 @@ __device__ __forceinline__ int closest_hit(const float4* __restrict__ nodes, int
         int tri = ~link;
         if (hit && link < 0) {
             Tri tr = load_tri(tris, tri);
+            tr.gmin = tr.gmin * dl;
             float t, u, v;
             if (tri_test(tr, o, d, t, u, v)) {
                 int fid = face_id[tri];

@@ -34,10 +34,36 @@ def write_obj(path, v, f):
             fh.write("f %d %d %d\n" % (t[0] + 1, t[1] + 1, t[2] + 1))
 
 
+def drop_coincident_faces(v, f, prefer=(0.0, 0.0, -1.0)):
+    """Faces as sets: of all faces over the same three vertices (any rotation, EITHER winding) keep one -- the one whose
+    normal points most along `prefer` (default -z: towards the wall z = 0 the scenes are seen from), first occurrence
+    on ties -- and drop faces of zero area (float32, the renderer's precision).  Vertex clustering flattens thin
+    features (the bunny's ears) into two coincident sheets of opposite winding; which of two coincident triangles a
+    ray hits is decided by the last bit of `t`, so such pairs make every visibility result a coin toss."""
+    v32 = np.asarray(v, dtype=np.float32)
+    f = np.asarray(f)
+    if f.size == 0:
+        return f
+    p0, p1, p2 = (v32[f[:, k]].astype(np.float64) for k in range(3))
+    n = np.cross(p1 - p0, p2 - p0)
+    area = np.linalg.norm(n, axis=1)
+    score = n @ np.asarray(prefer, dtype=np.float64)
+    key = np.sort(f, axis=1)
+    # stable lexicographic order over (vertex set, -score, original index): the first of each group wins
+    order = np.lexsort((np.arange(f.shape[0]), -score, key[:, 2], key[:, 1], key[:, 0]))
+    ks = key[order]
+    first = np.ones(f.shape[0], dtype=bool)
+    first[1:] = np.any(ks[1:] != ks[:-1], axis=1)
+    keep = np.zeros(f.shape[0], dtype=bool)
+    keep[order[first]] = True
+    keep &= area > 0
+    return f[keep]
+
+
 def cluster_decimate(v, f, cell):
     """Vertex clustering on a uniform grid of edge `cell`: vertices of a cell merge into
-    their mean, faces that collapse are dropped, duplicate faces are removed.  Winding is
-    preserved.  Deterministic (pure numpy, stable sorts)."""
+    their mean, faces that collapse are dropped, and of faces over the same vertex set (either winding) one
+    survives (drop_coincident_faces).  Winding is preserved.  Deterministic (pure numpy, stable sorts)."""
     v = np.asarray(v, dtype=np.float64)
     lo = v.min(axis=0)
     key3 = np.floor((v - lo) / cell).astype(np.int64)
@@ -48,12 +74,7 @@ def cluster_decimate(v, f, cell):
     nv = np.stack([np.bincount(inv, weights=v[:, c], minlength=uniq.size) / cnt for c in range(3)], axis=1)
     nf = inv[np.asarray(f, dtype=np.int64)]
     keep = (nf[:, 0] != nf[:, 1]) & (nf[:, 1] != nf[:, 2]) & (nf[:, 0] != nf[:, 2])
-    nf = nf[keep]
-    # drop duplicates regardless of rotation (keep first occurrence)
-    rot = np.argmin(nf, axis=1)
-    canon = np.stack([np.roll(r, -k) for r, k in zip(nf, rot)]) if nf.size else nf
-    _, first = np.unique(canon, axis=0, return_index=True)
-    nf = nf[np.sort(first)]
+    nf = drop_coincident_faces(nv, nf[keep])
     used = np.unique(nf)
     remap = -np.ones(nv.shape[0], dtype=np.int64)
     remap[used] = np.arange(used.size)

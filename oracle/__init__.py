@@ -6,6 +6,7 @@ status).  Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s
 ``cpu_baseline`` leg import this package, and only as the checker / reported CPU
 baseline.  Nothing under ``nlos_surface_optimization_amd/`` imports it.
 """
+import contextlib
 import ctypes
 import os
 import subprocess
@@ -33,10 +34,10 @@ class Opts(ctypes.Structure):
 
 def build(force=False):
     """Compile the oracle with gcc (recipe: oracle/Makefile)."""
-    src = os.path.join(_HERE, "nlos_oracle.c")
+    deps = [os.path.join(_HERE, "nlos_oracle.c"), os.path.join(_HERE, "nlos_oracle.h"),
+            os.path.join(_HERE, "..", "include", "nlos_contract.h")]
     if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)
-            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(os.path.join(_HERE, "nlos_oracle.h"))):
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps)):
         return _LIB_PATH
     subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
     return _LIB_PATH
@@ -52,6 +53,32 @@ def lib():
             getattr(_lib, name).restype = ctypes.c_float
             getattr(_lib, name).argtypes = [ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
     return _lib
+
+
+def set_graze_ratio(ratio):
+    """Grazing rule of the numeric contract (include/nlos_contract.h): ratio < 0 restores the contract's value,
+    0 switches the rule off (with accel=0: the reference's rule-free all-faces definition).  Process-global."""
+    f = lib().nlos_oracle_set_graze_ratio
+    f.argtypes = [ctypes.c_float]
+    f.restype = None
+    f(float(ratio))
+
+
+def graze_ratio():
+    f = lib().nlos_oracle_graze_ratio
+    f.restype = ctypes.c_float
+    return float(f())
+
+
+@contextlib.contextmanager
+def rule_free():
+    """with oracle.rule_free(): ... -- renders inside use the reference's rule-free hit test (Embree accepts every
+    den != 0, SMO/transient_and_gradient.cpp:199-206); call the renders with accel=0 for the all-faces definition."""
+    set_graze_ratio(0.0)
+    try:
+        yield
+    finally:
+        set_graze_ratio(-1.0)
 
 
 def make_opts(seed=0, source_offset=0, total_sources=0, accel=0, threads=0,

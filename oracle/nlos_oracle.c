@@ -21,6 +21,7 @@
  * GGX eval_nwdiff early-outs yield zero vectors (uninitialised in reference).
  */
 #include "nlos_oracle.h"
+#include "../include/nlos_contract.h"   /* NLOS_GRAZE_RATIO: the one constant both sides compile in */
 
 #include <math.h>
 #include <stdlib.h>
@@ -87,15 +88,20 @@ int nlos_oracle_num_bins(float lb, float ub, float res) {
 }
 
 /* ------------------------------------------------------------ triangle test */
-/* Grazing rule (numeric contract): a ray that meets a triangle's plane at less than
- * asin(2^-6) = 0.9 degrees does not hit it -- |ng . d| >= |ng| / 64 is part of the hit test, for the sampled face
- * and for occluders alike.  The reference (Embree) has no such rule.  It is what makes "closest hit over ALL
- * faces" well defined in fp32: t = T / den and the barycentrics are only as accurate as den, so for den -> 0 the
- * test reports hits millimetres away from the ray, which no culled query (BVH slabs, depth bounds, the GPU's
- * perspective grid) can be made to reproduce.  With the rule the reported hit is within ~1e-5 of the scene size
- * of the true one and every conservative cull -- padded by ten times that -- enumerates it.  Energy-wise the
- * excluded samples carry cos^2 < 2.5e-4 of a frontal sample's weight. */
-#define NLOS_GRAZE_RATIO 0.03125f               /* gmin = ratio * area = |ng| / 64 (area = |ng| / 2) */
+/* Grazing rule (numeric contract, DESIGN.md section 2, include/nlos_contract.h): a ray that meets a triangle's plane
+ * at less than asin(2^-10) = 0.056 degrees does not hit it -- |ng . d| >= |ng| |d| / 1024 is part of the hit test, for
+ * the sampled face and for occluders alike.  The reference (Embree) has no such rule
+ * (SMO/transient_and_gradient.cpp:199-206 accepts every hit rtcIntersect1M reports).  It is what makes "closest hit
+ * over ALL faces" reproducible in fp32: t = T / den and the barycentrics are only as accurate as den, so for
+ * den -> 0 the test reports hits millimetres away from the ray, which no culled query (BVH slabs, depth bounds, the
+ * GPU's perspective grid) can be made to follow.  With the rule the reported hit is within ~4e-4 t of the true one
+ * and every conservative cull is padded by a multiple of that.  Energy-wise an excluded sample carries
+ * cos^2 < 1e-6 of a frontal sample's weight.
+ * nlos_oracle_set_graze_ratio(0) switches the rule off: with accel == 0 (all faces, brute force) that is the
+ * reference's rule-free definition, against which tests/test_oracle.py bounds what the rule changes. */
+static float g_graze_ratio = NLOS_GRAZE_RATIO;      /* gmin = ratio * area = |ng| / 1024 (area = |ng| / 2) */
+void nlos_oracle_set_graze_ratio(float ratio) { g_graze_ratio = ratio < 0.0f ? NLOS_GRAZE_RATIO : ratio; }
+float nlos_oracle_graze_ratio(void) { return g_graze_ratio; }
 
 typedef struct { v3 p0, e1, e2, ng; float gmin; } tri_t;   /* e1 = p0-p1, e2 = p2-p0, ng = e2 x e1 */
 
@@ -105,7 +111,7 @@ static inline tri_t make_tri(v3 p0, v3 p1, v3 p2) {
     t.e1 = sub3(p0, p1);
     t.e2 = sub3(p2, p0);
     t.ng = cross3(neg3(t.e1), t.e2);     /* = cross(p1 - p0, p2 - p0) bit for bit (-e1 is p1 - p0 exactly) */
-    t.gmin = NLOS_GRAZE_RATIO * (sqrtf(dot3(t.ng, t.ng)) / 2.0f);
+    t.gmin = g_graze_ratio * (sqrtf(dot3(t.ng, t.ng)) / 2.0f);
     return t;
 }
 
@@ -114,7 +120,9 @@ static inline float flipsign(float x, int neg) { return neg ? -x : x; }
 /* Embree 3 Moeller-Trumbore, tnear = 0, tfar = inf (Row I).  Returns 1 on hit
  * and writes (t, u, v); u weights the 2nd, v the 3rd vertex
  * (SMO/transient_and_gradient.cpp:208-211). */
-static inline int tri_test(const tri_t *tr, v3 o, v3 d, float *t, float *u, float *v) {
+/* gscale: |d| for row E's unnormalised directions (the cut-off angle must not depend on the direction's length);
+ * the render paths pass unit directions and gscale = 1 (x * 1.0f is exact). */
+static inline int tri_test_scaled(const tri_t *tr, v3 o, v3 d, float gscale, float *t, float *u, float *v) {
     v3 c = sub3(tr->p0, o);
     v3 r = cross3(c, d);
     float den = dot3(tr->ng, d);
@@ -128,12 +136,16 @@ static inline int tri_test(const tri_t *tr, v3 o, v3 d, float *t, float *u, floa
     if (!(U + Vv <= aden)) return 0;
     float Tn = flipsign(dot3(tr->ng, c), sg);
     if (!(0.0f < Tn)) return 0;           /* absDen*tnear < T with tnear = 0 */
-    if (!(aden >= tr->gmin)) return 0;    /* grazing rule */
+    if (!(aden >= tr->gmin * gscale)) return 0;    /* grazing rule */
     float rcp = 1.0f / aden;
     *u = U * rcp;
     *v = Vv * rcp;
     *t = Tn * rcp;
     return 1;
+}
+
+static inline int tri_test(const tri_t *tr, v3 o, v3 d, float *t, float *u, float *v) {
+    return tri_test_scaled(tr, o, d, 1.0f, t, u, v);
 }
 
 /* -------------------------------------------------------------------- scene */
@@ -227,7 +239,7 @@ static int scene_init(scene_t *sc, const float *V, int nV, const int32_t *F, int
             float e = fmaxf(fabsf(slo[a]), fabsf(shi[a]));
             if (e > ext) ext = e;
         }
-        float pad = 1e-4f * ext + 1e-30f;   /* conservative: >> fp32 rounding of hit points */
+        float pad = 1.6e-3f * ext + 1e-30f;   /* conservative: >> fp32 rounding of hit points, > the grazing-rule error */
         sc->nodes = (bnode_t *)malloc(sizeof(bnode_t) * (size_t)(2 * nF));
         sc->n_nodes = 0;
         bvh_build_rec(sc, 0, nF, cent, pad);
@@ -249,14 +261,15 @@ static inline void hit_update(hit_t *h, int f, float t, float u, float v) {
     }
 }
 
-static hit_t closest_brute(const scene_t *sc, v3 o, v3 d) {
+static hit_t closest_brute_scaled(const scene_t *sc, v3 o, v3 d, float gscale) {
     hit_t h; h.prim = -1; h.t = INFINITY; h.u = h.v = 0.0f;
     for (int f = 0; f < sc->nF; ++f) {
         float t, u, v;
-        if (tri_test(&sc->tris[f], o, d, &t, &u, &v)) hit_update(&h, f, t, u, v);
+        if (tri_test_scaled(&sc->tris[f], o, d, gscale, &t, &u, &v)) hit_update(&h, f, t, u, v);
     }
     return h;
 }
+static hit_t closest_brute(const scene_t *sc, v3 o, v3 d) { return closest_brute_scaled(sc, o, d, 1.0f); }
 
 /* conservative slab test against padded boxes; never culls a box that holds a
  * triangle whose tri_test() hit has t <= tmax */
@@ -266,15 +279,15 @@ static inline int box_hit(const bnode_t *n, const float o[3], const float inv[3]
         float ta = (n->lo[a] - o[a]) * inv[a];
         float tb = (n->hi[a] - o[a]) * inv[a];
         float tn = fminf(ta, tb), tf = fmaxf(ta, tb);   /* fmin/fmax drop NaN (0*inf) */
-        tn = tn - fabsf(tn) * 1e-4f;                    /* >> the error of t under the grazing rule (~2e-5) */
-        tf = tf + fabsf(tf) * 1e-4f;
+        tn = tn - fabsf(tn) * 1.6e-3f;                  /* > the error of t under the grazing rule (~4e-4) */
+        tf = tf + fabsf(tf) * 1.6e-3f;
         if (tn > t0) t0 = tn;
         if (tf < t1) t1 = tf;
     }
     return t0 <= t1;
 }
 
-static hit_t closest_bvh(const scene_t *sc, v3 o, v3 d) {
+static hit_t closest_bvh_scaled(const scene_t *sc, v3 o, v3 d, float gscale) {
     hit_t h; h.prim = -1; h.t = INFINITY; h.u = h.v = 0.0f;
     if (sc->n_nodes == 0) return h;
     float of[3] = {o.x, o.y, o.z}, inv[3];
@@ -289,16 +302,18 @@ static hit_t closest_bvh(const scene_t *sc, v3 o, v3 d) {
             for (int i = n->first; i < n->first + n->count; ++i) {
                 int f = sc->order[i];
                 float t, u, v;
-                if (tri_test(&sc->tris[f], o, d, &t, &u, &v)) hit_update(&h, f, t, u, v);
+                if (tri_test_scaled(&sc->tris[f], o, d, gscale, &t, &u, &v)) hit_update(&h, f, t, u, v);
             }
         } else {
-            if (sp + 2 > 128) { /* cannot happen for median splits */ return closest_brute(sc, o, d); }
+            if (sp + 2 > 128) { /* cannot happen for median splits */ return closest_brute_scaled(sc, o, d, gscale); }
             stack[sp++] = n->left;
             stack[sp++] = n->right;
         }
     }
     return h;
 }
+
+static hit_t closest_bvh(const scene_t *sc, v3 o, v3 d) { return closest_bvh_scaled(sc, o, d, 1.0f); }
 
 static inline hit_t closest_hit(const scene_t *sc, v3 o, v3 d, int accel) {
     return accel ? closest_bvh(sc, o, d) : closest_brute(sc, o, d);
@@ -316,7 +331,11 @@ int nlos_oracle_intersect(const float *origins, const float *dirs, int n_rays,
     (void)threads;
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n_rays; ++i) {
-        hit_t h = closest_hit(&sc, ld3(origins + 3 * (size_t)i), ld3(dirs + 3 * (size_t)i), accel);
+        /* EMB/c_embree_intersector.cpp:20-45 hands the caller's direction to Embree as it is: any length */
+        const v3 d = ld3(dirs + 3 * (size_t)i);
+        const float dl = sqrtf(dot3(d, d));
+        hit_t h = accel ? closest_bvh_scaled(&sc, ld3(origins + 3 * (size_t)i), d, dl)
+                        : closest_brute_scaled(&sc, ld3(origins + 3 * (size_t)i), d, dl);
         if (out3) {
             if (h.prim < 0) out3[3 * (size_t)i] = -1.0f;
             else { out3[3 * (size_t)i] = (float)h.prim; out3[3 * (size_t)i + 1] = h.u; out3[3 * (size_t)i + 2] = h.v; }

@@ -15,7 +15,8 @@ Reads /root/reference (read-only, absent on the GPU box) and writes DATA only:
   adam_modified.npz   parameter trajectories of the reference's own optimiser class
                       (exp_bunny/adam_modified.py, imported and run on CPU) on fixed gradients
   oracle_cfg1.npz     oracle transient + gradient for BASELINE config 1 (regression pin)
-  oracle_bunny16.npz  oracle transient + gradient, bunny_5k, 16 sources (regression pin)
+  oracle_bunny16.npz  oracle transient + gradient, bunny_5k, 16 sources (regression pin), plus the same render under
+                      the reference's rule-free hit test (all faces, no grazing rule): the contract may not drift from it
   ggx_table.npz       oracle GGX eval / eval_adiff / eval_nwdiff over an (alpha, n.w) grid
 
 No reference source text is copied: the prototype is imported and executed, and only its
@@ -289,9 +290,19 @@ def make_oracle_bunny(v, f):
     weight = 0.5 + rs.random_sample(tr.shape)
     _, grad, _ = orc.render_gradient(origin, normal, v, f, 20000, lb, ub, res, data, weight, refine=10,
                                      sigma_bin=1, testing_flag=1, loss_flag=0, seed=0, accel=1, threads=1)
+    # the same render under the reference's RULE-FREE hit test (Embree accepts every den != 0,
+    # SMO/transient_and_gradient.cpp:199-206), all faces, brute force: pins the contract's grazing rule against drift
+    # (tests/test_oracle.py::test_contract_stays_within_tolerance_of_the_rule_free_fixture)
+    with orc.rule_free():
+        tr_rf, _ = orc.render_transient(origin, normal, v, f, 20000, lb, ub, res, seed=0, accel=0)
+        _, grad_rf, _ = orc.render_gradient(origin, normal, v, f, 20000, lb, ub, res, data, weight, refine=10,
+                                            sigma_bin=1, testing_flag=1, loss_flag=0, seed=0, accel=0)
     np.savez_compressed(os.path.join(HERE, "oracle_bunny16.npz"), origin=origin, normal=normal, lb=lb, ub=ub,
-                        res=res, num_sample=20000, transient=tr, data=data, weight=weight, gradient=grad)
-    print("bunny16 rows", tr.sum(axis=1)[:4], "grad", np.abs(grad).max())
+                        res=res, num_sample=20000, transient=tr, data=data, weight=weight, gradient=grad,
+                        transient_rule_free=tr_rf, gradient_rule_free=grad_rf)
+    print("bunny16 rows", tr.sum(axis=1)[:4], "grad", np.abs(grad).max(),
+          "| vs rule-free: rows %.2e grad %.2e" % (np.linalg.norm(tr - tr_rf) / np.linalg.norm(tr_rf),
+                                                   np.linalg.norm(grad - grad_rf) / np.linalg.norm(grad_rf)))
 
 
 def make_ggx_table():
@@ -321,6 +332,12 @@ if __name__ == "__main__":
         sys.exit(0)
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
+    if "--meshes-only" in sys.argv:
+        # the two fixture meshes and the oracle vectors that depend on them; the prototype / optimiser fixtures stay
+        bv, bf = make_meshes()
+        make_oracle_cfg1()
+        make_oracle_bunny(bv, bf)
+        sys.exit(0)
     bv, bf = make_meshes()
     make_pyref()
     make_pyref_nc()

@@ -11,7 +11,8 @@ import pytest
 from conftest import ROOT
 
 STANDIN = os.path.join(ROOT, "tests", "_bench_standin.py")
-SMALL = ["--grid", "4", "--num-sample", "5000", "--steps", "1", "--warmup", "0", "--sustain-seconds", "0", "--prewarm-seconds", "0"]
+SMALL = ["--grid", "4", "--num-sample", "5000", "--steps", "1", "--warmup", "0", "--sustain-seconds", "0", "--prewarm-seconds", "0",
+         "--share-steps", "0"]
 
 
 def _run(cmd, env=None, timeout=600):
@@ -39,7 +40,46 @@ def test_launcher_starts_two_ranks_and_reports_them(scaling):
     assert out["config"]["sources_total"] == (16 if scaling == "strong" else 32)
     assert out["value"] > 0 and out["ms_per_step"] >= max(out["per_rank_ms_per_step"]) - 1e-9
     assert out["parity"]["pass"] and out["parity"]["rows"] == (8 if scaling == "strong" else 16)
+    assert out["parity"]["ranks_gated"] == 2 and out["parity"]["all_ranks_pass"]      # every rank gates its own block
     assert "cpu_baseline" not in out                    # N > 1: no CPU leg
+
+
+def test_prewarm_runs_the_same_number_of_collectives_on_every_rank():
+    """the prewarm loop is bounded by wall time and every step holds an all-reduce -- the decision to
+    leave the loop must be collective, or two ranks that straddle the threshold hang.  Two gloo ranks, prewarm on."""
+    small = [a for a in SMALL]
+    small[small.index("--prewarm-seconds") + 1] = "0.3"
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.launch(%r, 2, script=%r, require_devices=False, timeout=500))"
+            % (ROOT, ["--gpus", "2"] + small, STANDIN))
+    p = _run([sys.executable, "-c", code])
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = _json_line(p.stdout)
+    assert out["n_gpus"] == 2 and out["parity"]["all_ranks_pass"]
+
+
+def test_one_ranks_share_and_the_share_table():
+    p = _run([sys.executable, STANDIN, "--gpus", "1", "--no-cpu-baseline", "--as-rank", "3", "--of", "4"] + SMALL)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = _json_line(p.stdout)
+    assert out["as_rank"]["sources"] == [12, 16] and out["parity"]["rows"] == 4 and out["parity"]["pass"]
+    assert "ONE RANK'S SHARE" in out["config"]["workload"] and "strong_share" not in out
+    small = [a for a in SMALL]
+    small[small.index("--share-steps") + 1] = "1"
+    p = _run([sys.executable, STANDIN, "--gpus", "1", "--no-cpu-baseline"] + small)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = _json_line(p.stdout)
+    sh = out["strong_share"]
+    assert [len(sh[k]["per_rank_ms"]) for k in ("2", "4", "8")] == [2, 4, 8] and sh["8"]["max_ms"] > 0
+
+
+def test_side_workloads_are_gated_too():
+    for extra in (["--forward-only"], ["--mesh", "mannequin"]):
+        p = _run([sys.executable, STANDIN, "--gpus", "1", "--no-cpu-baseline"] + extra + SMALL)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out = _json_line(p.stdout)
+        assert out["parity"]["pass"] and out["parity"]["rows"] >= 4
+        assert ("gradient_rel_l2" in out["parity"]) == (extra != ["--forward-only"])
 
 
 def test_single_rank_line_has_parity_and_no_launcher():

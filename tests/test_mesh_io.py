@@ -27,6 +27,25 @@ def test_fixture_meshes_are_wall_facing_closed_enough(bunny, mannequin):
     for v, f in (bunny, mannequin):
         assert f.min() >= 0 and f.max() < v.shape[0]
         assert v[:, 2].min() > 0.2          # in front of the wall z = 0
+        # no two faces over the same three vertices (coincident twins make visibility a coin toss of the last bit of t)
+        assert np.unique(np.sort(f, axis=1), axis=0).shape[0] == f.shape[0]
+        # no zero-area face, in the renderer's precision
+        p0, p1, p2 = (v[f[:, k]] for k in range(3))
+        n = np.cross(p1 - p0, p2 - p0)
+        assert (np.linalg.norm(n, axis=1) > 0).all()
+
+
+def test_coincident_faces_are_dropped_keeping_the_wall_facing_one():
+    from nlos_surface_optimization_amd import mesh_io
+    v = np.array([[0, 0, 1], [1, 0, 1], [0, 1, 1], [1, 1, 1.2], [2, 2, 1]], np.float32)
+    f = np.array([[0, 1, 2],        # normal +z (faces away from the wall z = 0)
+                  [1, 2, 3],
+                  [2, 1, 0],        # the twin of face 0, normal -z: this one stays
+                  [1, 2, 0],        # a rotation of face 0
+                  [0, 1, 4], [4, 1, 0],      # another pair
+                  [1, 1, 3]], np.int32)      # zero area
+    g = mesh_io.drop_coincident_faces(v, f)
+    assert g.tolist() == [[1, 2, 3], [2, 1, 0], [4, 1, 0]]
 
 
 def test_read_transient_mat_layouts(tmp_path):

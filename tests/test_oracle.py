@@ -106,6 +106,77 @@ def test_oracle_regression_vs_golden(orc, cfg1, bunny):
     assert rel_l2(tr, g["transient"]) < 1e-13 and rel_l2(gr, g["gradient"]) < 1e-11
 
 
+def test_contract_stays_within_tolerance_of_the_rule_free_fixture(orc, bunny):
+    """The committed rule-free vectors (all faces, no grazing rule: the reference's definition,
+    SMO/transient_and_gradient.cpp:199-206) pin the contract itself: whatever happens to the rule or the arithmetic,
+    the contract's render may not leave them by more than a tenth of the stated tolerance."""
+    v, f = bunny
+    g = np.load(os.path.join(GOLDEN, "oracle_bunny16.npz"))
+    tr, gr, _ = orc.render_gradient(g["origin"], g["normal"], v, f, int(g["num_sample"]), float(g["lb"]),
+                                    float(g["ub"]), float(g["res"]), g["data"], g["weight"], seed=0, accel=1)
+    assert rel_l2(tr, g["transient_rule_free"]) <= 1e-6
+    assert np.abs(tr - g["transient_rule_free"]).max() <= 1e-7 * g["transient_rule_free"].max()
+    assert rel_l2(gr, g["gradient_rule_free"]) <= 1e-6
+
+
+@pytest.mark.timeout(2400)      # three all-faces brute-force renders of 100 sources: ~5 minutes on 8 cores
+def test_grazing_rule_stays_inside_the_tolerance_of_the_rule_free_definition(orc, bunny, mannequin):
+    """for every BASELINE mesh / window the contract (grazing rule of
+    include/nlos_contract.h) against the oracle with the rule switched off, all faces, brute force -- the reference's
+    semantics (Embree accepts every den != 0).  100 sources each.  (profiles/r03_graze_sweep.json holds the same
+    table for cut-offs 2^-6 ... 2^-11; tools/graze_sweep.py.)"""
+    bv, bf = bunny
+    mv, mf = mannequin
+    cases = [("bunny 512 bins", bv, bf, 0.25, 0.625, 1.625, 2.0 ** -9, {}),
+             ("mannequin +-0.35 1024 bins", mv, mf, 0.35, 0.0, 1024 * 2.4e-3, 2.4e-3, {}),
+             ("bunny GGX 1024 bins", bv, bf, 0.25, 0.625, 1.625, 2.0 ** -10, dict(ggx_alpha=0.3))]
+    assert abs(orc.graze_ratio() - 2.0 ** -9) < 1e-12
+    for name, v, f, half, lb, ub, res, kw in cases:
+        origin, normal = grid_sources(10, half)
+        t_con, _ = orc.render_transient(origin, normal, v, f, 20000, lb, ub, res, seed=0, accel=1, **kw)
+        rs = np.random.RandomState(3)
+        data = t_con * (1.0 + 0.3 * rs.standard_normal(t_con.shape))
+        weight = 0.5 + rs.random_sample(t_con.shape)
+        t_con2, g_con, _ = orc.render_gradient(origin, normal, v, f, 20000, lb, ub, res, data, weight, seed=0, accel=1, **kw)
+        assert np.array_equal(t_con, t_con2)
+        with orc.rule_free():       # one call: rows and gradient of the rule-free all-faces definition
+            t_free, g_free, _ = orc.render_gradient(origin, normal, v, f, 20000, lb, ub, res, data, weight, seed=0, accel=0, **kw)
+        rows = np.linalg.norm(t_con - t_free, axis=1) / np.linalg.norm(t_free, axis=1)
+        assert rel_l2(t_con, t_free) <= 1e-6, name
+        assert rows.max() <= 1e-5, name
+        assert np.abs(t_con - t_free).max() <= 1e-6 * t_free.max(), name
+        assert rel_l2(g_con, g_free) <= 1e-6, name
+        assert t_free.sum() > 0
+
+
+def test_row_e_prim_ids_against_the_rule_free_definition_and_direction_length(orc, bunny):
+    """Row E (embree_intersector): how many primIDs does the grazing rule change on 1e5 random rays (the reference hands
+    the rays to Embree, which has no rule), and -- ADVICE round 2 -- the rule must not depend on |d|: the reference
+    passes directions of any length (EMB/c_embree_intersector.cpp:20-45)."""
+    v, f = bunny
+    rs = np.random.RandomState(17)
+    n = 100000
+    o = np.zeros((n, 3), np.float32)
+    o[:, :2] = rs.uniform(-0.3, 0.3, (n, 2))
+    tgt = v[rs.randint(0, v.shape[0], n)] + rs.normal(0, 0.01, (n, 3)).astype(np.float32)
+    d = (tgt - o).astype(np.float32)
+    a = orc.intersect(o, d, v, f, accel=1, short=True)
+    with orc.rule_free():
+        b = orc.intersect(o, d, v, f, accel=0, short=True)
+    differing = int((a != b).sum())
+    assert differing <= 2, differing            # measured: 0 of 100 000 at the 2^-10 cut-off
+    # powers of two scale every product exactly: identical decisions, identical barycentrics
+    full = orc.intersect(o, d, v, f, accel=1)
+    for s in (2.0 ** -7, 2.0 ** 7):
+        sc = orc.intersect(o, (d * np.float32(s)).astype(np.float32), v, f, accel=1)
+        assert np.array_equal(np.nan_to_num(sc, nan=-7), np.nan_to_num(full, nan=-7))
+    # any other length: the same hits up to the rounding of the scaled direction (never "all rays miss")
+    for s in (0.01, 100.0):
+        sc = orc.intersect(o, (d * np.float32(s)).astype(np.float32), v, f, accel=1, short=True)
+        assert (sc != a).mean() < 1e-3
+        assert (sc >= 0).mean() > 0.5
+
+
 def test_flipped_plane_is_dark(orc, cfg1):
     c = cfg1
     tr, _ = orc.render_transient(c["origin"], c["normal"], c["v"], np.ascontiguousarray(c["f"][:, [0, 2, 1]]), 256,
