@@ -392,14 +392,13 @@ def run_rank(args, backend):
         return 1
 
     def step():
-        grad.zero_()
         if args.forward_only:
             r.render_transient(origin, normal, verts, faces, args.num_sample, lb, ub, res,
                                source_offset=lo, total_sources=L_total, **nc)
         else:
             r.render_gradient(origin, normal, verts, faces, args.num_sample, lb, ub, res, data=data,
                               weight=weight, refine_scale=10, sigma_bin=1, testing_flag=1, loss_flag=0,
-                              gradient=grad, source_offset=lo, total_sources=L_total, **nc)
+                              gradient=grad, zero_gradient=True, source_offset=lo, total_sources=L_total, **nc)
             if world > 1:
                 dist.all_reduce(grad, op=dist.ReduceOp.SUM)
 
@@ -477,10 +476,9 @@ def run_rank(args, backend):
                 d_k, w_k = data[klo:khi].contiguous(), weight[klo:khi].contiguous()
 
                 def step_k():
-                    grad.zero_()
                     r.render_gradient(o_k, n_k, verts, faces, args.num_sample, lb, ub, res, data=d_k, weight=w_k,
                                       refine_scale=10, sigma_bin=1, testing_flag=1, loss_flag=0, gradient=grad,
-                                      source_offset=klo, total_sources=L_total)
+                                      zero_gradient=True, source_offset=klo, total_sources=L_total)
                 for _ in range(3):
                     step_k()
                 backend.sync()

@@ -296,6 +296,12 @@ typedef struct nlos_render_args {
     /* stale-cache protection for reuse_bvh / reuse_visibility: the values nlos_ctx_mesh_generation() /
      * nlos_ctx_visibility_generation() returned after the render whose tree / cache is to be reused */
     int64_t mesh_generation, visibility_generation;
+    /* 1: `gradient` is overwritten instead of accumulated into (GRADIENT / VERTEX_GRADIENT modes; v1's semantics,
+     * stratified_transient_raytracer/stratifiedStreamedGradientRenderer.cpp:419, which GRADIENT_V1 always has).  The
+     * zeroing rides in the residual kernel of the same render: an optimisation loop that calls with zero_gradient = 1
+     * holds no separate fill operation per step. */
+    int32_t zero_gradient;
+    int32_t reserved0;
 } nlos_render_args;
 
 int  nlos_sizeof_render_args(void);                 /* for FFI layout checks */

@@ -72,6 +72,8 @@ class RenderArgs(ctypes.Structure):
         ("jitter_length", ctypes.c_int32),
         ("mesh_generation", ctypes.c_int64),
         ("visibility_generation", ctypes.c_int64),
+        ("zero_gradient", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
     ]
 
 

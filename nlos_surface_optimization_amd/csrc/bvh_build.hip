@@ -324,7 +324,16 @@ __global__ __launch_bounds__(ST) void k_sort_scatter(const uint32_t* __restrict_
 // chip-wide launches finish the job -- the tree (one thread per inner node) and the refit (one thread per
 // leaf; the bottom-up walk is then as long as the deepest chain, ~35 levels, instead of F/1024 walks per
 // thread: 8.6 M cycles -> ~0.1 ms at F = 79 k).
-__global__ __launch_bounds__(256) void k_build_tree(BuildArgs a) {
+// records of a lazy build: one thread per sorted leaf (what k_build_refit does for its leaves, without the tree)
+__global__ __launch_bounds__(256) void k_build_records(BuildArgs a) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.F) return;
+    float lb6[6];
+    leaf_records(a, a.idx0, j, 0.0f, lb6);
+}
+
+__global__ __launch_bounds__(256) void k_build_tree(BuildArgs a, int conditional) {
+    if (conditional && a.need_tree && __hip_atomic_load(a.need_tree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     const int F = a.F, n_int = F - 1;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) a.parent[F > 1 ? 0 : n_int] = -1;
@@ -334,7 +343,8 @@ __global__ __launch_bounds__(256) void k_build_tree(BuildArgs a) {
     karras_node(a, a.keys0, F, i, left, right, last_unused);
 }
 
-__global__ __launch_bounds__(256) void k_build_refit(BuildArgs a) {
+__global__ __launch_bounds__(256) void k_build_refit(BuildArgs a, int conditional) {
+    if (conditional && a.need_tree && __hip_atomic_load(a.need_tree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     const int F = a.F, n_int = F - 1;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= F) return;
@@ -552,7 +562,19 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, 
     const int* order = idx_in;
     NLOS_STAMP();
     if (split) {
-        if (tid == 0) a.box[6 * (size_t)(2 * F - 1)] = pad;      // for k_build_refit
+        if (tid == 0) {
+            a.box[6 * (size_t)(2 * F - 1)] = pad;      // for k_build_refit
+            if (a.lazy) {
+                // The root box -- all the perspective grid reads of the tree (source_frame()).  Bit for bit what the refit
+                // arrives at: the union of the leaves' padded boxes, and x -> fl(x -/+ pad) is monotonic.
+                a.nodes[0] = make_float4(s_bounds[0] - pad, s_bounds[1] - pad, s_bounds[2] - pad, s_bounds[3] + pad);
+                a.nodes[1] = make_float4(s_bounds[4] + pad, s_bounds[5] + pad, __int_as_float(-1), __int_as_float(F > 1 ? 1 : ~0));
+                if (a.need_tree) *a.need_tree = 0;
+                if (a.host_status)
+                    __hip_atomic_store(a.host_status, __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
         return;
     }
 
@@ -758,6 +780,15 @@ bool launch_build_bvh(const BuildArgs& a, hipStream_t stream) {
     if (lds > lds_max) lds = (size_t)RCNT_WORDS * sizeof(uint32_t);      // the sort then goes through global scratch
     if (refit > lds && refit <= lds_max) lds = refit;
     const int split = (refit > lds_max && a.F > 1) ? 1 : 0;      // beyond the LDS refit: chip-wide launches
+    if (a.lazy && a.F > 1 && ((size_t)RCNT_WORDS + 3 * (size_t)a.F + 4) * sizeof(uint32_t) <= lds_max && a.F <= KF * BT) {
+        // lazy: the single-workgroup front end (bounds, keys, in-LDS sort, root box), then the records chip-wide
+        const size_t lds_sort = ((size_t)RCNT_WORDS + 3 * (size_t)a.F + 4) * sizeof(uint32_t);
+        note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_bvh), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_sort), "hipFuncSetAttribute(dynamic LDS)");
+        hipLaunchKernelGGL(k_build_bvh, dim3(1), dim3(BT), lds_sort, stream, a, (int)(lds_sort / sizeof(uint32_t)), 1);
+        hipLaunchKernelGGL(k_build_records, dim3((a.F + 255) / 256), dim3(256), 0, stream, a);
+        return a.host_status != nullptr;
+    }
     if (!split) {
         note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_bvh), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds), "hipFuncSetAttribute(dynamic LDS)");
@@ -782,9 +813,15 @@ bool launch_build_bvh(const BuildArgs& a, hipStream_t stream) {
         std::swap(kin, kout);
         std::swap(iin, iout);
     }
-    hipLaunchKernelGGL(k_build_tree, dim3((a.F + 255) / 256), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(k_build_refit, dim3((a.F + 255) / 256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_build_tree, dim3((a.F + 255) / 256), dim3(256), 0, stream, a, 0);
+    hipLaunchKernelGGL(k_build_refit, dim3((a.F + 255) / 256), dim3(256), 0, stream, a, 0);
     return false;
+}
+
+void launch_build_tree(const BuildArgs& a, bool conditional, hipStream_t stream) {
+    if (a.F <= 1) return;
+    hipLaunchKernelGGL(k_build_tree, dim3((a.F + 255) / 256), dim3(256), 0, stream, a, conditional ? 1 : 0);
+    hipLaunchKernelGGL(k_build_refit, dim3((a.F + 255) / 256), dim3(256), 0, stream, a, conditional ? 1 : 0);
 }
 
 }  // namespace nlos

@@ -414,6 +414,15 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
         g.pady = kSubFrac + kSlopeAbs * (float)kSub * g.inv_ch;
     };
 
+    if (!TILED && !frame_ok && a.need_tree && a.retry && pass < last_pass) {
+        // lazy scene build: the tree does not exist yet.  This source (scene not strictly in front of its wall point)
+        // needs the BVH query: flag it for the second launch, in front of which the tree is completed
+        if (tid == 0) {
+            a.retry[blockIdx.x] = pass + 1;
+            __hip_atomic_store(a.need_tree, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return false;
+    }
     if (COARSE) set_grid_res(max(8, (R * 3) >> 2));      // the lists overflowed at R_launch: start one step coarser
     if (rows_in_lds)
         for (int i = tid; i < nbins; i += NT) s_row[i] = 0.0;
@@ -495,10 +504,13 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             load_face_tri<FEAT>(a.sc, jg, f, tr_unused);
             const bool dark = face_dark(f);
             live = !dark;
-            // does this source see the face at |cos| < 2^-6 somewhere (graze_scale() > 1)?  One compare on the plane
-            // distance face_dark() has just formed; the counting pass reads the flag instead of testing every triangle again
-            const bool grazing = !(fabsf(dot(f.fn, o - f.p0)) >= fr.hmin);
-            if (frame_ok && !(TILED && ident)) g_cov[j] = grazing ? (uint16_t)1 : (uint16_t)0;
+            // The margin scale of this face as an occluder (graze_scale(): 1 unless the source sees it at |cos| < 2^-6),
+            // evaluated HERE, once, where the vertices and the normal are in registers, and handed to the counting and
+            // the fill pass as a 16-bit fixed-point number (64ths, rounded up) in the live list's scratch, which is free
+            // until the bucket placement behind the fill pass.  (Testing in those passes instead -- a dependent record
+            // load and a divergent region in two thirds of their wave iterations -- cost 7 % of the kernel.)
+            const float msv = graze_scale(o, f.p0, f.p1, f.p2, f.fn, fr.hmin);
+            if (frame_ok && !(TILED && ident)) g_live[j] = (uint16_t)ceilf(msv * 64.0f);
 #ifdef NLOS_DIAG_NO_DARKZERO       // diagnostic builds only
             if (false) {
 #else
@@ -516,7 +528,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 // the largest depth at which an own hit of this face can be REPORTED: its farthest vertex, plus the error
                 // of t at the face's grazing angle
                 const float zfar = fmaxf(fmaxf(f.p0.z, f.p1.z), f.p2.z) - o.z;
-                const float msf = grazing ? graze_scale(o, f.p0, f.p1, f.p2, f.fn, fr.hmin) : 1.0f;
+                const float msf = msv;
                 const uint32_t zb = __float_as_uint(fmaxf(zfar, 0.0f) * (1.0f + kDepthEps * msf) + 1e-30f);
                 const Proj2 q = project_tri(o, f.p0, f.p1, f.p2);
                 raster_tri_coarse(g, R2, q, [&](int cx, int cy) { atomicMax(&s_zc[cy * R2 + cx], zb); });
@@ -559,8 +571,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     const int jg = gid(j);
                     const float4 q0 = a.sc.facerec[4 * jg], q1 = a.sc.facerec[4 * jg + 1], q2 = a.sc.facerec[4 * jg + 2];
                     const float zfar = fmaxf(fmaxf(q0.z, q1.y), q2.x) - o.z;
-                    const float4 q3 = a.sc.facerec[4 * jg + 3];
-                    const float msf = graze_scale(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), mk(q3.y, q3.z, q3.w), fr.hmin);
+                    const float msf = (float)g_live[j] * (1.0f / 64.0f);          // the setup pass's margin scale of this face
                     const uint32_t zb = __float_as_uint(fmaxf(zfar, 0.0f) * (1.0f + kDepthEps * msf) + 1e-30f);
                     const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
                     raster_tri_coarse(g, R2, q, [&](int cx, int cy) { atomicMax(&s_zc[cy * R2 + cx], zb); });
@@ -579,23 +590,19 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
 #endif
                 const int j = gid(jl);
                 const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
+                // the setup pass's margin scale of this triangle -- requested BEFORE the store below: loads and stores
+                // return in order (vmcnt), so a load behind the store would wait for the store's round trip to the L2
+                const uint16_t msq = g_live[jl];
                 if (pend_jl >= 0) g_cov[pend_jl] = pend_cov;       // the previous triangle's cells, behind this one's loads (see the trace)
-                // margins of this triangle as an occluder: x 1 unless the source sees it at less than 0.9 degrees (flagged by
-                // the setup pass; after a coarsening restart the flags are gone -- the coverage words took their place --
-                // and every triangle is tested)
-                float ms = 1.0f;
-                if (attempt > 0 || g_cov[jl] != 0) {
-                    const float4 q3 = a.sc.facerec[4 * j + 3];
-                    ms = graze_scale(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), mk(q3.y, q3.z, q3.w), fr.hmin);
-                }
+                // margins of this triangle as an occluder: x 1 unless the source sees it at less than 0.9 degrees
+                const float ms = (float)msq * (1.0f / 64.0f);
                 const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
                 // smallest depth at which a hit on it can be REPORTED (its nearest vertex, minus the error of t)
                 const uint32_t zn = __float_as_uint(fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f) * (1.0f - kDepthEps * ms));
                 // the cells the triangle enters are remembered for the fill pass (16 bits per triangle in global
                 // scratch): a bit per cell of a bounding box of up to 4 x 4 cells, relative to its first cell (which
-                // the fill pass re-derives from the projection); 0xFFFF = rasterise again (larger boxes, the
-                // rare box that is entered in all sixteen cells, and every triangle with scaled margins: the fill pass
-                // then knows that a replayed mask means ms == 1)
+                // the fill pass re-derives from the projection, with the same margin scale); 0xFFFF = rasterise again
+                // (larger boxes, and the rare box that is entered in all sixteen cells)
                 int bx0 = 0, by0 = 0;
                 bool big = false, reach = false;
                 uint32_t cv = 0u;
@@ -606,7 +613,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     }
                 }, [&](int cx0, int cx1, int cy0, int cy1) -> bool {
                     bx0 = cx0; by0 = cy0;
-                    big = cx1 - cx0 > 3 || cy1 - cy0 > 3 || ms > 1.0f;
+                    big = cx1 - cx0 > 3 || cy1 - cy0 > 3;
                     reach = reachable(zn)(cx0, cx1, cy0, cy1);
                     return reach;
                 });
@@ -647,7 +654,11 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     if (frame_ok && !(TILED && ident) && s_ctl[1] != 0) {
         if (!COARSE && R > 8) return true;                     // cell lists overflow: once more, coarser, right here
         if (pass < last_pass && a.retry) {
-            if (tid == 0) a.retry[blockIdx.x] = pass + 1;      // still too many entries: redo in the big-LDS launch
+            if (tid == 0) {
+                a.retry[blockIdx.x] = pass + 1;      // still too many entries: redo in the big-LDS launch
+                // (which may have to fall back to the BVH query: a lazily built scene gets its tree now)
+                if (a.need_tree) __hip_atomic_store(a.need_tree, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             return false;
         }
     }
@@ -672,6 +683,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             // what the counting pass found: nothing to enter (about half of the triangles: the far side of the
             // object), a mask of up to 4 x 4 cells, or a large bounding box that is rasterised again
             const uint32_t cov = g_cov[jl];
+            const uint16_t msq = g_live[jl];
             const bool counts_as_live = fill_buckets && ((s_mask[jl >> 6] >> (jl & 63)) & 1ull);
             if (cov == 0u && !counts_as_live) continue;
             uint32_t nmax = 0u;                              // longest list among the cells the triangle enters
@@ -679,12 +691,8 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 const int j = gid(jl);
                 const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
                 const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
-                // a replayed coverage mask means base margins (the counting pass sends every scaled triangle here as 0xFFFF)
-                float ms = 1.0f;
-                if (cov == 0xFFFFu) {
-                    const float4 q3 = a.sc.facerec[4 * j + 3];
-                    ms = graze_scale(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), mk(q3.y, q3.z, q3.w), fr.hmin);
-                }
+                // the margin scale the counting pass used (the same 16-bit number)
+                const float ms = (float)msq * (1.0f / 64.0f);
                 const float zmin_rel = fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f) * (1.0f - kDepthEps * ms);
                 const uint32_t zn = __float_as_uint(zmin_rel);
                 const uint32_t zq = (uint32_t)min(max((int)floorf((zmin_rel - g.z0) * g.inv_qz) - 1, 0), g.zmax);
@@ -702,13 +710,13 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     }, reachable(zn));
                 } else {
                     int bx0, by0;
-                    raster_origin(g, q, 1.0f, bx0, by0);
+                    raster_origin(g, q, ms, bx0, by0);
                     for (uint32_t m = cov; m; m &= m - 1u) {
                         const int bit = __ffs((int)m) - 1;
                         const int xx = bx0 + (bit & 3), yy = by0 + (bit >> 2);
                         const int c = yy * R + xx;
                         uint32_t pos = atomicAdd(&s_cell[c], 1u);
-                        s_ent[pos] = make_entry(g, bb, xx, yy, zq, jl, 1.0f);
+                        s_ent[pos] = make_entry(g, bb, xx, yy, zq, jl, ms);
                         if (len_ok) nmax = max(nmax, (uint32_t)s_len8[c]);
                     }
                 }
@@ -1202,6 +1210,8 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
     const int last_pass = a.retry ? 1 : 0;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, false, 0>), dim3(a.src.L), dim3(kGridNT), lds, stream, a, rows_in_lds, R,
                        (int)cap - kScan, 0, last_pass);
+    // lazy scene build: the tree follows now if a first-launch workgroup asked for it (two launches that leave at once otherwise)
+    if (a.retry && a.need_tree && note.lazy_build) launch_build_tree(*note.lazy_build, true, stream);
     if (a.retry)      // sources whose cell lists overflowed even on the coarsened grid: once more with the whole CU's LDS
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, false, 1>), dim3(a.src.L), dim3(kGridNT), lds_big, stream, a,
                            rows_in_lds, R, (int)((lds_big - fixed) / 4) - kScan, 1, last_pass);

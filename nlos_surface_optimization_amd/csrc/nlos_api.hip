@@ -78,6 +78,12 @@ struct nlos_ctx {
     DevBuf keys0, keys1, idx0, idx1, child, range, parent, arrive, box, status;
     DevBuf nodes, tris, facerec, face_id, tri_zmin;
     int built_F = -1, built_V = -1;
+    // lazy scene build: the grid back-end reads the sorted records and the root box only, so a render
+    // that will use it builds just those; tree_complete == false means nodes[] beyond the root may not exist.  The
+    // launchers complete the tree when a back-end needs it (lazy_args: what that takes).
+    bool tree_complete = false;
+    nlos::BuildArgs lazy_args;
+    DevBuf lazy_flag;
     // stale-cache protection: every scene build / recorded pass 1 takes the next value of one counter
     int64_t gen_counter = 0, mesh_gen = 0, vis_gen = 0;
     // what the last render did (nlos_ctx_last_path)
@@ -210,11 +216,23 @@ int check_status(nlos_ctx* c, bool wait) {
     return NLOS_OK;
 }
 
-int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bool reuse, int64_t reuse_gen, hipStream_t st) {
+int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bool reuse, int64_t reuse_gen, hipStream_t st,
+               bool lazy = false) {
     if (reuse) {
         // the caller vouches that vertices/faces are those of generation reuse_gen; any build since then
         // (another mesh, another vertex position) makes that claim stale
-        if (c->built_F == nF && c->built_V == nV && reuse_gen != 0 && reuse_gen == c->mesh_gen) return NLOS_OK;
+        if (c->built_F == nF && c->built_V == nV && reuse_gen != 0 && reuse_gen == c->mesh_gen) {
+            if (!c->tree_complete) {
+                // a lazily built scene: completing the tree reads the mesh again -- through THIS call's pointers
+                c->lazy_args.vertices = V; c->lazy_args.faces = F;
+                if (!lazy) {
+                    nlos::launch_build_tree(c->lazy_args, false, st);
+                    HIP_TRY(hipGetLastError());
+                    c->tree_complete = true;
+                }
+            }
+            return NLOS_OK;
+        }
         return fail(NLOS_ERR_ARG, "nlos_render: reuse_bvh requested but the context no longer holds the tree of that "
                                   "mesh generation (pass the value nlos_ctx_mesh_generation() returned after the render to reuse)");
     }
@@ -235,6 +253,7 @@ int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bo
     rc |= c->facerec.ensure(sizeof(float4) * 4 * (size_t)nF);
     rc |= c->face_id.ensure(sizeof(int) * (size_t)nF);
     rc |= c->tri_zmin.ensure(sizeof(float) * (size_t)nF);
+    rc |= c->lazy_flag.ensure(sizeof(int) * 4);
     if (rc) return NLOS_ERR_HIP;
     // status[0] (bad face index) is sticky until the host has reported it; the rest is scratch its users initialise
     if (c->status_clear) { HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int), st)); c->status_clear = false; }
@@ -259,7 +278,12 @@ int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bo
     b.nodes = c->nodes.as<float4>(); b.tris = c->tris.as<float4>(); b.facerec = c->facerec.as<float4>();
     b.face_id = c->face_id.as<int>();
     b.tri_zmin = c->tri_zmin.as<float>();
+    // lazy: only where the single-workgroup front end applies (the chip-wide builder of larger meshes always finishes)
+    b.lazy = (lazy && nF >= 64 && nF <= 6144) ? 1 : 0;
+    b.need_tree = c->lazy_flag.as<int>();
     const bool status_stored = nlos::launch_build_bvh(b, st);
+    c->tree_complete = !b.lazy;
+    c->lazy_args = b;
     HIP_TRY(hipGetLastError());
 #ifdef NLOS_BUILD_STAMPS
     {   // diagnostic builds only: per-phase cycles of the build kernel
@@ -488,8 +512,13 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     c->path_retry_workgroups = 0;
 
     mark(c, 0, st);
-    rc = ensure_bvh(c, a->vertices, nV, a->faces, nF, a->reuse_bvh != 0, a->mesh_generation, st);
+    static const int tile_threshold_b = [] { const char* e = std::getenv("NLOS_TILE_THRESHOLD"); return e ? std::atoi(e) : 6200; }();
+    static const bool lazy_enabled = [] { const char* e = std::getenv("NLOS_LAZY_TREE"); return !e || std::atoi(e) != 0; }();
+    // the single-workgroup grid back-end reads the records and the root box only: build the tree when (if) it is needed
+    const bool lazy_build = lazy_enabled && nF <= tile_threshold_b && a->force_bvh != 1;
+    rc = ensure_bvh(c, a->vertices, nV, a->faces, nF, a->reuse_bvh != 0, a->mesh_generation, st, lazy_build);
     if (rc) return rc;
+    if (!c->tree_complete) note.lazy_build = &c->lazy_args;
     mark(c, 1, st);
 
     nlos::SourceView src;
@@ -530,6 +559,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.tile_list = nullptr;
     fa.tile_count = nullptr;
     fa.retry = nullptr;
+    fa.need_tree = c->tree_complete ? nullptr : c->lazy_flag.as<int>();
     fa.tiles_x = fa.tiles_y = fa.tile_cap = 0;
     static const int tile_threshold = [] { const char* e = std::getenv("NLOS_TILE_THRESHOLD"); return e ? std::atoi(e) : 6200; }();
     int chunk_L = L > 0 ? L : 1;                       // sources per pass-1 launch
@@ -656,6 +686,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     c->path.tiles = note.tiles; c->path.tile_cap = note.tile_cap; c->path.chunks = n_chunks;
     c->path.rows_in_lds = note.rows_in_lds;
     c->path_retry_workgroups = note.retry_workgroups;
+    if (note.tree_built) c->tree_complete = true;
 #ifdef NLOS_FWD_STAMPS
     {
         long long h[24];
@@ -707,11 +738,20 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         }
     }
     const double* diff_ptr = a->residual;
-    if (needs_grad && a->residual && a->pathlengths) {
+    // zero_gradient: the output is cleared by the residual kernel of this render (no fill operation of its own)
+    double* zero_ptr = nullptr;
+    size_t zero_n = 0;
+    if (a->zero_gradient && (mode == NLOS_MODE_GRADIENT || mode == NLOS_MODE_VERTEX_GRADIENT)) {
+        zero_ptr = a->gradient;
+        zero_n = mode == NLOS_MODE_GRADIENT ? 3 * (size_t)nV : 3 * (size_t)T;
+    }
+    if (needs_grad && a->residual && (a->pathlengths || zero_ptr)) {
         nlos::ResidualArgs ra;
         std::memset(&ra, 0, sizeof(ra));
         ra.pathlengths = a->pathlengths; ra.L = 0; ra.T = T; ra.lb = lb; ra.res = res;
+        ra.zero = zero_ptr; ra.zero_n = zero_n;
         nlos::launch_residual(ra, st);
+        zero_ptr = nullptr;
     }
     if (needs_grad && !a->residual) {
         rc = c->diff.ensure(sizeof(double) * (size_t)L * T + 16);
@@ -723,9 +763,12 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         ra.loss_test = mode == NLOS_MODE_GRADIENT_V1 ? 0 : a->loss_test;
         ra.lb = lb; ra.res = res;
         ra.w_width = mode == NLOS_MODE_GRADIENT_V1 ? a->w_width : 0;
+        ra.zero = zero_ptr; ra.zero_n = zero_n;
         nlos::launch_residual(ra, st);
+        zero_ptr = nullptr;
         diff_ptr = c->diff.as<double>();
     }
+    if (zero_ptr) nlos::launch_zero_f64(zero_ptr, zero_n, st);      // (a mode without a residual launch)
     mark(c, 3, st);
 
     // ---- pass 2 -----------------------------------------------------------------------

@@ -11,6 +11,10 @@ namespace nlos {
 struct LaunchNote {
     int backend = 0, reason = 0, grid_R = 0, tiles = 0, tile_cap = 0, rows_in_lds = 0, gradient_kernel = 0;
     int retry_workgroups = 0;        // entries of the retry / path-code array the grid launches wrote
+    // lazy scene build (grid back-end): the records exist, the tree does not yet.  The launchers complete it -- on a
+    // device-side flag between the grid's two launches, unconditionally in front of a BVH back-end
+    const struct BuildArgs* lazy_build = nullptr;
+    bool tree_built = false;         // set when the tree was completed unconditionally
     hipError_t err = hipSuccess;
     const char* err_what = nullptr;
 };
@@ -33,6 +37,9 @@ struct BuildArgs {
     int* arrive;             // [F-1]
     float* box;              // [6*(2F-1) + 8]
     int* status;             // [1] bit0: face index out of range
+    int lazy;                // 1: bounds, keys, sort, records and the root box only (what the perspective grid reads); the tree
+                             //    follows by launch_build_tree() if somebody needs occluded() / closest_hit()
+    int* need_tree;          // lazy builds: device word the grid kernels raise when a workgroup needs the BVH query (or null)
     int* host_status;        // device-visible pinned host word (or null): the single-workgroup builder leaves status[0] there on its way out
     // outputs
     float4* nodes;           // [2*(2F-1)]  pre-order, 32 B per node
@@ -43,6 +50,9 @@ struct BuildArgs {
 };
 // true: the kernel itself stored the status word to a.host_status (no copy needed behind the build)
 bool launch_build_bvh(const BuildArgs& a, hipStream_t stream);
+// completes a lazy build (tree, refit, node emission; chip-wide kernels).  conditional: the kernels leave at once
+// unless *a.need_tree != 0
+void launch_build_tree(const BuildArgs& a, bool conditional, hipStream_t stream);
 
 // ------------------------------------------------------------------ rendering
 struct SceneView {
@@ -98,6 +108,8 @@ struct ForwardArgs {
     int* tile_count;         // [L * tiles] subset sizes (may exceed tile_cap: overflow), filled by k_tile_bin
     int tiles_x, tiles_y, tile_cap;
     int* retry;              // [workgroups] flags of the big-LDS second launch (grid kernels) or null
+    int* need_tree;          // lazy scene build: raised by first-launch workgroups that need the BVH query (they then leave it to
+                             // the second launch, in front of which the tree is completed); null = the tree exists
 };
 void launch_forward(const ForwardArgs& a, hipStream_t stream);
 // the two back-ends behind launch_forward (forward_grid.hip returns false when the BVH back-end is needed)
@@ -125,6 +137,8 @@ struct ResidualArgs {
     int loss_test;
     float lb, res;
     int w_width;             // > 0: box(2w+1) (*) box(2w+1) per row, 'same' crop
+    double* zero;            // [zero_n] or null: cleared by the same launch (the gradient output of zero_gradient renders)
+    size_t zero_n;
 };
 void launch_residual(const ResidualArgs& a, hipStream_t stream);
 

@@ -74,6 +74,8 @@ __global__ __launch_bounds__(256) void k_residual(ResidualArgs a) {
     }
     if (a.pathlengths && blockIdx.x == 0)
         for (int i = threadIdx.x; i < a.T; i += blockDim.x) a.pathlengths[i] = (double)(a.lb + i * a.res);
+    if (a.zero)
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.zero_n; i += stride) a.zero[i] = 0.0;
 }
 
 __global__ __launch_bounds__(256) void k_boxfilter(double* diff, int T, int w) {
@@ -151,6 +153,11 @@ void launch_forward(const ForwardArgs& a, hipStream_t stream) {
     if (tl_note) tl_note->rows_in_lds = rows_in_lds;
     if (launch_forward_grid(a, rows_in_lds, stream)) return;
     if (tl_note) tl_note->backend = 3;       // NLOS_PATH_BVH; the reason was recorded by the grid dispatcher
+    if (tl_note && tl_note->lazy_build && !tl_note->tree_built) {
+        // the scene was built for the grid (records only): the BVH back-end needs the tree after all
+        launch_build_tree(*tl_note->lazy_build, false, stream);
+        tl_note->tree_built = true;
+    }
     launch_forward_bvh(a, rows_in_lds, stream);
 }
 

@@ -185,8 +185,9 @@ class TransientRenderer:
                         resolution, data=None, weight=None, refine_scale=10, sigma_bin=1, testing_flag=1,
                         loss_flag=0, vertex_normal=None, albedo=None, alpha=None, gradient=None,
                         normal_term=-1, residual=None, reuse_visibility=False, reuse_bvh=False,
-                        mesh_generation=0, visibility_generation=0, **kw):
-        """Rows D,G,GD. Returns (transient, gradient [V,3] f64 (accumulated into if given), pathlengths).
+                        mesh_generation=0, visibility_generation=0, zero_gradient=False, **kw):
+        """Rows D,G,GD. Returns (transient, gradient [V,3] f64 (accumulated into if given -- overwritten with
+        zero_gradient=True: the render clears it itself, no fill operation of its own --), pathlengths).
         `reuse_bvh` / `reuse_visibility` need the generations read after the render whose tree / cache they
         reuse (mesh_generation(), visibility_generation()); with reuse_visibility pass 1 is skipped and the
         returned transient is None."""
@@ -202,10 +203,12 @@ class TransientRenderer:
         transient = None if reuse_visibility else torch.empty((L, T), dtype=torch.float64, device=self.device)
         path = torch.empty(T, dtype=torch.float64, device=self.device)
         if gradient is None:
-            gradient = torch.zeros((vertices.shape[0], 3), dtype=torch.float64, device=self.device)
+            gradient = torch.empty((vertices.shape[0], 3), dtype=torch.float64, device=self.device)
+            zero_gradient = True
         else:
             _want(gradient, torch.float64, "gradient", 2)
             assert tuple(gradient.shape) == (vertices.shape[0], 3), "gradient dimension should be Vx3"
+        a.zero_gradient = 1 if zero_gradient else 0
         a.data, a.weight, a.residual = _dptr(data), _dptr(weight), _dptr(residual)
         a.transient, a.pathlengths, a.gradient = _dptr(transient), _dptr(path), _dptr(gradient)
         a.testing_flag, a.loss_test, a.normal_term = int(testing_flag), int(loss_flag), int(normal_term)

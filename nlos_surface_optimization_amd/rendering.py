@@ -151,18 +151,6 @@ def space_carving_projection(v, space_carving_mesh):
     v[index, 2] = np.maximum(intersection_p[index, 2], v[index, 2])
 
 
-def create_weighting_function(data, gamma=1):
-    """exp_bunny/rendering.py:208-217 (host numpy, as in the reference)."""
-    eps = 0.1
-    i_max = np.max(data)
-    normalized_data = data / i_max
-    weight = (normalized_data + eps) ** gamma
-    total = np.sum(weight)
-    weight = weight / total
-    weight *= data.shape[0] * data.shape[1]
-    return weight
-
-
 def renderStreamedNormalSmoothing(mesh):
     """exp_bunny/rendering.py:298-301; mesh.f_affinity is the int32 [F,3] neighbour table
     (cgal_api.face_affinity in the reference, mesh_io.face_affinity here)."""
@@ -179,16 +167,13 @@ def renderStreamedCurvatureGradient(mesh):
 
 
 def create_weighting_function(data, gamma=1):
-    """exp_bunny/rendering.py:208-217 (host numpy, as in the reference; device twin:
-    device.TransientRenderer.create_weighting_function)."""
-    eps = 0.1
-    i_max = np.max(data)
-    normalized_data = data / i_max
-    weight = (normalized_data + eps) ** gamma
-    total = np.sum(weight)
-    weight = weight / total
-    weight *= data.shape[0] * data.shape[1]
-    return weight
+    """Per-bin loss weights of the measured transient `data` [L, T] (the interface of exp_bunny/rendering.py:208-217):
+    bins are weighted by (data / max(data) + 0.1) ** gamma and the weights rescaled to mean 1, so gamma = 0 gives
+    all ones.  Host numpy like the reference's; the device twin is device.TransientRenderer.create_weighting_function
+    (csrc/optimiser.hip)."""
+    data = np.asarray(data)
+    w = np.power(data / data.max() + 0.1, gamma)
+    return w * (w.size / w.sum())
 
 
 def evaluate_loss_with_normal_smoothness(gt_transient, weight, transient, smoothing_val, mesh, render_opt):

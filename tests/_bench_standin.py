@@ -23,7 +23,7 @@ class OracleStandIn:
 
     def render_gradient(self, origin, normal, vertices, faces, num_sample, lb, ub, res, data=None, weight=None,
                         refine_scale=10, sigma_bin=1, testing_flag=1, loss_flag=0, gradient=None, source_offset=0,
-                        total_sources=0, seed=None, **kw):
+                        total_sources=0, seed=None, zero_gradient=False, **kw):
         import oracle
         t, g, p = oracle.render_gradient(origin.numpy(), normal.numpy(), vertices.numpy(), faces.numpy(), num_sample,
                                          lb, ub, res, data.numpy(), weight.numpy(), refine=refine_scale,
@@ -32,6 +32,8 @@ class OracleStandIn:
                                          seed=self.seed if seed is None else seed)
         g = torch.from_numpy(g)
         if gradient is not None:
+            if zero_gradient:
+                gradient.zero_()
             gradient += g
             g = gradient
         return torch.from_numpy(t), g, torch.from_numpy(p)

@@ -4,6 +4,8 @@
 Reads /root/reference (read-only, absent on the GPU box) and writes DATA only:
   bunny_5k.npz        decimated exp_bunny/gt_bunny.obj (~5k faces), the cfg2/3 mesh
   mannequin.npz       exp_mannequin/cnlos_mannequin_threshold.obj (620 v / 1055 f), cfg4 mesh
+  mannequin_measurement.npz  exp_mannequin/transient.mat: the 4096 wall points and the measured photon counts, folded to
+                      1024 bins (cfg4's real inputs)
   pyref_angular.npz   inputs + outputs of the reference's numpy prototype
                       transient_rendering_python/rendering.py:angular_sampling (imported from
                       /root/reference) on the cfg1 plane and on the toy mesh of
@@ -62,6 +64,19 @@ def make_meshes():
     np.savez_compressed(os.path.join(HERE, "mannequin.npz"), v=mv, f=mf)
     print("mannequin", mv.shape, mf.shape)
     return nv, nf
+
+
+def make_mannequin_measurement():
+    """BASELINE configuration 4's real inputs: the reference's measured mannequin transient
+    (exp_mannequin/transient.mat: `lighting` [4096, 3] on +-0.35 m, uint8 photon counts [4096, 2048] at 1.2 mm) read
+    with the package's own reader and folded pairwise to 1024 bins of 2.4 mm, as exp_s/test.py:20-36 consumes such
+    files.  Data only."""
+    m = mesh_io.read_transient_mat(os.path.join(REF, "transient_rendering_cython/exp_mannequin/transient.mat"), fold=2)
+    counts = m["transient"]
+    assert counts.shape == (4096, 1024) and counts.max() < 256 and np.array_equal(counts, np.round(counts))
+    np.savez_compressed(os.path.join(HERE, "mannequin_measurement.npz"), lighting=m["lighting"],
+                        counts=counts.astype(np.uint8), lb=np.float32(0.0), res=np.float32(2.4e-3))
+    print("mannequin measurement", counts.shape, "photons", int(counts.sum()), "max", int(counts.max()))
 
 
 def make_pyref():
@@ -332,6 +347,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
+    if "--measurement-only" in sys.argv:
+        make_mannequin_measurement()
+        sys.exit(0)
     if "--meshes-only" in sys.argv:
         # the two fixture meshes and the oracle vectors that depend on them; the prototype / optimiser fixtures stay
         bv, bf = make_meshes()
@@ -339,6 +357,7 @@ if __name__ == "__main__":
         make_oracle_bunny(bv, bf)
         sys.exit(0)
     bv, bf = make_meshes()
+    make_mannequin_measurement()
     make_pyref()
     make_pyref_nc()
     make_pyref_grad()

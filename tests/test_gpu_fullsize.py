@@ -154,6 +154,47 @@ def test_config4_mannequin_64x64_1024_bins_confocal_and_pairs_two_blocks(mannequ
     r.close()
 
 
+def test_config4_on_the_references_own_measurement(mannequin, orc):
+    """cfg 4 on its REAL inputs: the 4096 wall points and the measured photon counts of the reference's
+    exp_mannequin/transient.mat (tests/golden/mannequin_measurement.npz: `lighting` on +-0.35 m, uint8 counts folded
+    pairwise to 1024 bins of 2.4 mm, consumed as exp_s/test.py:20-36 consumes such files: raw counts as `data`, the
+    loss weighting of exp_bunny/rendering.py:208-217 at gamma = 0).  Confocal (the reference-parity case), whole and as
+    two source blocks summed like the all-reduce, against the live oracle."""
+    import os
+    import torch
+    from conftest import GOLDEN
+    from nlos_surface_optimization_amd import device as nd, rendering
+    from nlos_surface_optimization_amd.dist import shard_bounds
+    v, f = mannequin
+    m = np.load(os.path.join(GOLDEN, "mannequin_measurement.npz"))
+    o = np.ascontiguousarray(m["lighting"], np.float32)
+    n = np.ascontiguousarray(np.tile(np.array([0, 0, 1], np.float32), (o.shape[0], 1)))
+    data = np.ascontiguousarray(m["counts"], np.float64)
+    L = o.shape[0]
+    assert o.shape == (4096, 3) and data.shape == (4096, 1024) and abs(float(np.abs(o[:, :2]).max()) - 0.35) < 1e-6
+    lb, res = float(m["lb"]), float(m["res"])
+    ub = float(np.float32(1024) * np.float32(res))
+    ns = 20000
+    w = np.ascontiguousarray(rendering.create_weighting_function(data, 0))
+    t_ref, g_ref, _ = orc.render_gradient(o, n, v, f, ns, lb, ub, res, data, w, accel=1, seed=0)
+    r = nd.TransientRenderer(torch.device("cuda", 0), seed=0)
+    to, tn, tv, tf, td, tw = _tensors(o, n, v, f, data, w)
+    t_g, grad, _ = r.render_gradient(to, tn, tv, tf, ns, lb, ub, res, data=td, weight=tw)
+    _check(t_g.cpu().numpy(), t_ref, grad.cpu().numpy(), g_ref)
+    gsum, rows = torch.zeros_like(grad), []
+    for rank in range(2):
+        lo, hi = shard_bounds(L, rank, 2)
+        t, g, _ = r.render_gradient(to[lo:hi].contiguous(), tn[lo:hi].contiguous(), tv, tf, ns, lb, ub, res,
+                                    data=td[lo:hi].contiguous(), weight=tw[lo:hi].contiguous(),
+                                    source_offset=lo, total_sources=L)
+        rows.append(t)
+        gsum += g
+    _check(torch.cat(rows).cpu().numpy(), t_ref, gsum.cpu().numpy(), g_ref)
+    # the measured rows really are what the render is compared with: the residual's mass is the data's
+    assert data.sum() > 1e6 and t_ref.sum() < 1e-3 * data.sum()
+    r.close()
+
+
 def test_config5_bunny_ggx_64x64_1024_bins_poisson_noised(bunny, orc):
     """cfg 5: GGX branch (alpha 0.3), 64x64 sources x 1024 bins, measurement = Poisson-noised clean transient +
     background (exp_noise/noise/addNoiseExample.m:9; numpy default_rng(0)), vertex gradient and d/d alpha."""

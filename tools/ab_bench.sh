@@ -13,7 +13,7 @@ for round in 1 2; do
   i=0
   for flags in "$@"; do
     d=/tmp/nlos_ab_$i
-    (cd $d && python3 bench.py --steps ${AB_STEPS:-10} --warmup 2 --no-cpu-baseline ${AB_ARGS:-} 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('variant $i [$flags] round $round: %.2f Gs/s  %.3f ms' % (d['value']/1e9, d['ms_per_step']), {k: round(v,3) for k,v in d['roofline']['kernel_ms'].items()})")
+    (cd $d && python3 bench.py --steps ${AB_STEPS:-10} --warmup 2 --no-cpu-baseline --share-steps 0 ${AB_ARGS:-} 2>$d/err.log | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('variant $i [$flags] round $round: %.2f Gs/s  %.3f ms' % (d['value']/1e9, d['ms_per_step']), {k: round(v,3) for k,v in d['roofline']['kernel_ms'].items()})" || tail -5 $d/err.log)
     i=$((i+1))
   done
 done
