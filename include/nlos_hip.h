@@ -119,10 +119,11 @@ int nlos_v1_streamed_render_transient(float *origin, int numSources, float *norm
 
 /* stratified_transient_raytracer/stratifiedTransientRenderer.h (v1, NOT streamed: one wall point, rows are
  * 1-D; renderer.pyx:93-102 `renderTransient`, still called by stratified_transient_raytracer/test.py:37).
- * Same estimator as the v1 streamed forward for numSources = 1 (unclamped form factor, face normals, no
- * albedo).  The reference body (stratifiedTransientRenderer.cpp:26-130) bins with the length of the SAMPLED
- * point and normalises the direction by a division; this entry uses the streamed kernel's hit-point length and
- * reciprocal multiply: identical but for a sample whose half path length sits within 1 ulp of a bin edge. */
+ * Unclamped form factor, face normals, no albedo.  The reference body (stratifiedTransientRenderer.cpp:96-124) takes
+ * path length, bin and barycentrics from the SAMPLED point of the stratified map, not from the hit Embree reports
+ * back; so does this entry (nlos_render_args.v1_sampled_point; oracle option `sampled_point`).  Remaining deviation: the
+ * ray direction is normalised by a multiply with the IEEE reciprocal, as everywhere in the contract, where the v1
+ * body divides. */
 int nlos_v1_render_transient(float *origin, float *normal, float *vertices, int numVertices,
         int *triangles, int numTriangles, int numSamples, float lowerBound, float upperBound,
         float resolution, double *transient, double *pathlengths);
@@ -301,10 +302,23 @@ typedef struct nlos_render_args {
      * zeroing rides in the residual kernel of the same render: an optimisation loop that calls with zero_gradient = 1
      * holds no separate fill operation per step. */
     int32_t zero_gradient;
-    int32_t reserved0;
+    /* 1 (TRANSIENT mode, confocal): the v1 NON-streamed forward body of renderTransient
+     * (stratified_transient_raytracer/stratifiedTransientRenderer.cpp:96-124): path length, bin, shading normal and albedo
+     * come from the SAMPLED point of the stratified map, not from the hit the intersector reports back (the two differ by
+     * the rounding of the hit's barycentrics, i.e. a sample within ~1e-7 of a bin edge changes bins).  Runs on the BVH
+     * back-end; nlos_v1_render_transient sets it together with clamp = 0. */
+    int32_t v1_sampled_point;
 } nlos_render_args;
 
 int  nlos_sizeof_render_args(void);                 /* for FFI layout checks */
+/* Deferred status of the device-pointer path.  nlos_render() cannot validate face indices on the host: the scene
+ * build reads an out-of-range index as vertex 0 (nothing faults), raises a flag, and the flag travels to the host
+ * behind the build.  It is reported -- as NLOS_ERR_ARG, once -- by the first of: a later nlos_render() that finds it
+ * arrived (that render returns before it enqueues anything: ITS outputs are untouched, and the mesh at fault is the
+ * one of an EARLIER call on this context), nlos_ctx_check(), nlos_ctx_timing_mean(), nlos_ctx_last_path(count = 1).
+ * The render that read the bad mesh itself returns NLOS_OK with outputs computed as if the index were 0.  Callers
+ * that cannot vouch for their indices call nlos_ctx_check() after the render (it synchronises).  A stream-captured
+ * render never reports (the graph replays without the host looking on). */
 void nlos_render_args_init(nlos_render_args *a);   /* zero + defaults (clamp=1, normal_term=-1, refine=1, sigma_bin=1) */
 
 /* Enqueue one render on `stream` (hipStream_t as void*; NULL = default stream).

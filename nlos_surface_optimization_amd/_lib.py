@@ -73,7 +73,7 @@ class RenderArgs(ctypes.Structure):
         ("mesh_generation", ctypes.c_int64),
         ("visibility_generation", ctypes.c_int64),
         ("zero_gradient", ctypes.c_int32),
-        ("reserved0", ctypes.c_int32),
+        ("v1_sampled_point", ctypes.c_int32),
     ]
 
 

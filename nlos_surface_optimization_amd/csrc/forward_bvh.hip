@@ -135,8 +135,24 @@ __global__ __launch_bounds__(256) void k_forward(ForwardArgs a, int rows_in_lds)
                 float t_self = 0.0f;
                 bool ok = s < spt;
                 if (ok)
-                    ok = sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, lb, ub, a.sc.vertex_normal,
-                                          a.sc.albedo, g, t_self);
+                    ok = sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, a.sp.sampled_point ? -3.0e38f : lb,
+                                          a.sp.sampled_point ? 3.0e38f : ub, a.sc.vertex_normal, a.sc.albedo, g, t_self);
+                if (ok && a.sp.sampled_point) {
+                    // v1 non-streamed body (stratified_transient_raytracer/stratifiedTransientRenderer.cpp:91-124): the SAMPLED
+                    // point's barycentrics and distance instead of the reported hit's (same ray, same visibility query)
+                    float S, T;
+                    sample_st(a.sp.seed, kbase + (uint64_t)s, S, T);
+                    const float sq = sqrtf(T);
+                    g.u = 1 - sq; g.v = (1 - S) * sq; g.w = S * sq;
+                    const V3 p = bary(g.u, f.p0, g.v, f.p1, g.w, f.p2);
+                    const V3 dq = p - o;
+                    g.h = sqrtf(dot(dq, dq));
+                    ok = (g.h <= ub / 2.0f) && (g.h >= lb / 2.0f);
+                    if (FEAT & FEAT_VN)
+                        g.n = bary(g.u, ld3(a.sc.vertex_normal + 3 * (size_t)f.i0), g.v, ld3(a.sc.vertex_normal + 3 * (size_t)f.i1), g.w,
+                                   ld3(a.sc.vertex_normal + 3 * (size_t)f.i2));
+                    if (FEAT & FEAT_ALB) g.alb = g.u * a.sc.albedo[f.i0] + g.v * a.sc.albedo[f.i1] + g.w * a.sc.albedo[f.i2];
+                }
                 float vv = 0.0f;
                 int bb = -1;
                 if (ok) {

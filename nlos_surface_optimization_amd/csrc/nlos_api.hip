@@ -367,7 +367,7 @@ void nlos_ctx_destroy(nlos_ctx* c) {
     DeviceGuard g(c->device);
     DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                      &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov};
+                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag};
     for (DevBuf* b : all) b->release();
     for (DevBuf& b : c->io) b.release();
     for (hipEvent_t& e : c->ring) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
@@ -380,7 +380,7 @@ int64_t nlos_ctx_scratch_bytes(const nlos_ctx* c) {
     if (!c) return 0;
     const DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                            &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov};
+                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag};
     int64_t s = 0;
     for (const DevBuf* b : all) s += (int64_t)b->cap;
     for (const DevBuf& b : c->io) s += (int64_t)b.cap;
@@ -435,7 +435,8 @@ int nlos_ctx_timing_mean(nlos_ctx* c, float* ms4, int* count) {
     }
     for (int i = 0; i < 4; ++i) ms4[i] = (float)(acc[i] / c->ring_count);
     if (count) *count = c->ring_count;
-    return NLOS_OK;
+    // this call has waited for the renders' events: a bad-face-index flag of any of their scene builds has arrived
+    return check_status(c, true);
 }
 
 void nlos_render_args_init(nlos_render_args* a) {
@@ -515,7 +516,8 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     static const int tile_threshold_b = [] { const char* e = std::getenv("NLOS_TILE_THRESHOLD"); return e ? std::atoi(e) : 6200; }();
     static const bool lazy_enabled = [] { const char* e = std::getenv("NLOS_LAZY_TREE"); return !e || std::atoi(e) != 0; }();
     // the single-workgroup grid back-end reads the records and the root box only: build the tree when (if) it is needed
-    const bool lazy_build = lazy_enabled && nF <= tile_threshold_b && a->force_bvh != 1;
+    const bool v1_point = a->v1_sampled_point && mode == NLOS_MODE_TRANSIENT && !a->sensor;      // BVH back-end only
+    const bool lazy_build = lazy_enabled && nF <= tile_threshold_b && a->force_bvh != 1 && !v1_point;
     rc = ensure_bvh(c, a->vertices, nV, a->faces, nF, a->reuse_bvh != 0, a->mesh_generation, st, lazy_build);
     if (rc) return rc;
     if (!c->tree_complete) note.lazy_build = &c->lazy_args;
@@ -529,6 +531,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     nlos::SampleParams sp;
     sp.seed = a->seed; sp.spt = spt; sp.lb = lb; sp.ub = ub;
     sp.clamp = a->clamp; sp.use_ggx = a->use_ggx; sp.ggx_alpha = a->ggx_alpha;
+    sp.sampled_point = (a->v1_sampled_point && mode == NLOS_MODE_TRANSIENT && !a->sensor) ? 1 : 0;
 
     const float* vn = a->vertex_normal;
     const float* alb = a->albedo;
@@ -552,7 +555,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.sp.nbins = rb;
     fa.vis = nullptr; fa.vis_words = vis_words;
     fa.intensity = a->intensity; fa.mode_intensity = mode == NLOS_MODE_INTENSITY ? 1 : 0;
-    fa.force_bvh = a->force_bvh == 1 ? 1 : 0;
+    fa.force_bvh = (a->force_bvh == 1 || v1_point) ? 1 : 0;
     fa.dbg = nullptr;
     fa.live = nullptr;
     fa.cov = nullptr;
@@ -563,7 +566,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.tiles_x = fa.tiles_y = fa.tile_cap = 0;
     static const int tile_threshold = [] { const char* e = std::getenv("NLOS_TILE_THRESHOLD"); return e ? std::atoi(e) : 6200; }();
     int chunk_L = L > 0 ? L : 1;                       // sources per pass-1 launch
-    if (nF <= tile_threshold && a->force_bvh != 1) {
+    if (nF <= tile_threshold && a->force_bvh != 1 && !v1_point) {
         rc = c->live.ensure(sizeof(uint16_t) * (size_t)(L > 0 ? L : 1) * nF + 16);
         if (!rc) rc = c->cov.ensure(sizeof(uint16_t) * (size_t)(L > 0 ? L : 1) * nF + 16);
         if (!rc) rc = c->tile_count.ensure(sizeof(int) * (size_t)(L > 0 ? L : 1) + 16);
@@ -571,7 +574,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         fa.live = c->live.as<uint16_t>();
         fa.cov = c->cov.as<uint16_t>();
         fa.retry = c->tile_count.as<int>();
-    } else if (a->force_bvh != 1 && L > 0) {
+    } else if (a->force_bvh != 1 && !v1_point && L > 0) {
         // tiled grid: ~3000 triangles per slope-space tile on average (small tiles leave the 512 threads idle); the densest tiles of a closed surface
         // (front + back side, several depth layers) hold up to ~4.5x the mean, and the subset capacity is bounded by
         // the 14-bit entry index (overflowing tiles fall back to the BVH query by themselves);
@@ -856,6 +859,10 @@ int nlos_ctx_last_path(nlos_ctx* c, nlos_path_info* out, int count_workgroups) {
     std::vector<int> h((size_t)n);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h.data(), flags, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    {   // a synchronising entry point: report a pending bad-face-index flag here rather than in some later render
+        const int rcs = check_status(c, true);
+        if (rcs) return rcs;
+    }
     out->workgroups = n; out->coarsened = 0; out->big_lds = 0; out->bvh_queries = 0;
     for (int v : h) {
         if (v == 1) ++out->big_lds;
@@ -1034,6 +1041,7 @@ struct HostRender {
     float lb = 0, ub = 0, res = 1;
     double *transient = nullptr, *pathlengths = nullptr, *gradient = nullptr, *intensity = nullptr, *scalar = nullptr;
     int refine = 1, sigma_bin = 1, testing_flag = 0, loss_test = 0, use_ggx = 0, clamp = 1, w_width = 0, vertex_num = -1;
+    int sampled_point = 0;
     float alpha = 0;
 };
 
@@ -1080,6 +1088,7 @@ int host_render(const HostRender& h) {
     a.testing_flag = h.testing_flag; a.loss_test = h.loss_test;
     a.normal_term = -1; a.clamp = h.clamp; a.use_ggx = h.use_ggx; a.ggx_alpha = h.alpha;
     a.vertex_num = h.vertex_num; a.w_width = h.w_width;
+    a.v1_sampled_point = h.sampled_point;
     if (hc.rc) return hc.rc;
     if (h.L == 0) {
         // nothing to render: outputs keep the reference's semantics (transient is [0,T])
@@ -1378,10 +1387,15 @@ int nlos_v1_streamed_render_transient(float* origin, int numSources, float* norm
 int nlos_v1_render_transient(float* origin, float* normal, float* vertices, int numVertices, int* triangles,
                              int numTriangles, int numSamples, float lowerBound, float upperBound, float resolution,
                              double* transient, double* pathlengths) {
-    // stratified_transient_raytracer/stratifiedTransientRenderer.cpp:132-218: one source, rows [numBins]
-    return nlos_v1_streamed_render_transient(origin, 1, normal, vertices, numVertices, nullptr, nullptr, triangles,
-                                             numTriangles, numSamples, lowerBound, upperBound, resolution, transient,
-                                             pathlengths);
+    // stratified_transient_raytracer/stratifiedTransientRenderer.cpp:132-218: one source, rows [numBins]; the body
+    // (:96-124) bins with the SAMPLED point's distance, unclamped
+    HostRender h;
+    h.mode = NLOS_MODE_TRANSIENT; h.clamp = 0; h.sampled_point = 1;
+    h.origin = origin; h.L = 1; h.normal = normal; h.vertices = vertices; h.V = numVertices;
+    h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.transient = transient; h.pathlengths = pathlengths;
+    return host_render(h);
 }
 
 static int host_intersect(float* origins, float* directions, int num_ray, float* vertices, int num_vertices,

@@ -85,6 +85,7 @@ struct SampleParams {
     int clamp;               // 1: v2 clamped form factor
     int use_ggx;
     float ggx_alpha;
+    int sampled_point;       // 1: v1 non-streamed forward body (path length, bin, normal, albedo from the SAMPLED point); BVH back-end only
 };
 
 // forward (rows S, I, F): histogram rows + optional visibility cache

@@ -29,6 +29,7 @@ class Opts(ctypes.Structure):
         ("ggx_alpha", ctypes.c_float),
         ("normal_term", ctypes.c_int32),
         ("clamp", ctypes.c_int32),
+        ("sampled_point", ctypes.c_int32),
     ]
 
 
@@ -82,7 +83,7 @@ def rule_free():
 
 
 def make_opts(seed=0, source_offset=0, total_sources=0, accel=0, threads=0,
-              ggx_alpha=None, normal_term=-1, clamp=1):
+              ggx_alpha=None, normal_term=-1, clamp=1, sampled_point=0):
     o = Opts()
     o.seed = seed
     o.source_offset = source_offset
@@ -93,6 +94,7 @@ def make_opts(seed=0, source_offset=0, total_sources=0, accel=0, threads=0,
     o.ggx_alpha = 0.0 if ggx_alpha is None else float(ggx_alpha)
     o.normal_term = normal_term
     o.clamp = clamp
+    o.sampled_point = sampled_point
     return o
 
 

@@ -519,13 +519,19 @@ static inline v3 sample_dir(const task_t *t, float S, float T) {
 /* accepted-hit geometry shared by all kernels (SMO/...:206-223) */
 typedef struct { float u, v, w, h; v3 dir, n; float alb; } geo_t;
 
-static inline int accept_sample(const task_t *t, const scene_t *sc, int f, int accel,
-                                float S, float T, float lb, float ub, geo_t *g) {
+static inline int accept_sample_ex(const task_t *t, const scene_t *sc, int f, int accel,
+                                   float S, float T, float lb, float ub, geo_t *g, int sampled_point) {
     v3 dir = sample_dir(t, S, T);
     hit_t h = closest_hit(sc, t->o, dir, accel);
     if (h.prim != f) return 0;
     g->v = h.u; g->w = h.v;
     g->u = 1.0f - g->v - g->w;
+    if (sampled_point) {
+        /* STR/stratifiedTransientRenderer.cpp:91-101,108-124: halfLength = |point - origin| of the sampled point, and
+         * u, v, w of the sample map weight the normals / albedos */
+        float sq = sqrtf(T);
+        g->u = 1 - sq; g->v = (1 - S) * sq; g->w = S * sq;
+    }
     v3 p = bary3(g->u, t->p0, g->v, t->p1, g->w, t->p2);
     v3 d = sub3(p, t->o);
     g->h = sqrtf(dot3(d, d));
@@ -536,6 +542,10 @@ static inline int accept_sample(const task_t *t, const scene_t *sc, int f, int a
     g->alb = 1.0f;
     if (t->has_alb) g->alb = g->u * t->a0 + g->v * t->a1 + g->w * t->a2;
     return 1;
+}
+static inline int accept_sample(const task_t *t, const scene_t *sc, int f, int accel,
+                                float S, float T, float lb, float ub, geo_t *g) {
+    return accept_sample_ex(t, sc, f, accel, S, T, lb, ub, g, 0);
 }
 
 static inline float emax0(float x) { return 0.0f < x ? x : 0.0f; }   /* embree::max(0.f, x) */
@@ -556,7 +566,7 @@ static void forward_task(const scene_t *sc, const float *origin, const float *no
         float S, T;
         geo_t g;
         nlos_oracle_sample(op->seed, kbase + (uint64_t)s, &S, &T);
-        if (!accept_sample(&t, sc, f, op->accel, S, T, lb, ub, &g)) continue;
+        if (!accept_sample_ex(&t, sc, f, op->accel, S, T, lb, ub, &g, op->sampled_point)) continue;
         float ff = -dot3(g.n, g.dir) * dot3(t.on, g.dir) / g.h / g.h;
         if (op->clamp) ff = emax0(ff);
         int bin = (int)floorf((2.0f * g.h - lb) / res);

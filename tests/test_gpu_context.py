@@ -212,4 +212,14 @@ def test_device_path_surfaces_a_bad_face_index(bunny):
     t2, _ = r.render_transient(to, tn, tv, tf, ns, LB, UB, RES)
     r.check()
     assert rel_l2(t2.cpu().numpy(), t.cpu().numpy()) <= 1e-12
+    # the synchronising entry points report it too: nobody has to remember check()
+    r.render_transient(to, tn, tv, bad, ns, LB, UB, RES)
+    with pytest.raises(_lib.NlosError, match="face index out of range"):
+        r.last_path(count=True)
+    r.enable_timing(True)
+    r.timing_reset()
+    r.render_transient(to, tn, tv, bad, ns, LB, UB, RES)
+    with pytest.raises(_lib.NlosError, match="face index out of range"):
+        r.timing_mean_ms()
+    r.check()
     r.close()

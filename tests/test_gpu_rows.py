@@ -143,8 +143,12 @@ def test_v1_rows_w_and_g1(mannequin, orc):
     # v1 non-streamed renderTransient (stratified_transient_raytracer/renderer.pyx:93-102): ONE wall point, 1-D rows
     row, path1 = np.zeros(Tn), np.zeros(Tn)
     renderer_v1.renderTransient(np.ascontiguousarray(origin[4]), np.ascontiguousarray(normal[4]), v, f, ns, lb, ub, res, row, path1)
-    t_1, p_1 = orc.render_transient(origin[4:5], normal[4:5], v, f, ns, lb, ub, res, clamp=0, accel=1)
-    assert t_1.sum() > 0 and rel_l2(row, t_1[0]) <= 1e-5 and np.array_equal(path1, p_1)
+    # ... whose body bins with the SAMPLED point's distance (stratifiedTransientRenderer.cpp:96-124): the oracle restates that
+    # body too (sampled_point=1), and the rows agree to summation order -- no sample sits in another bin
+    t_1, p_1 = orc.render_transient(origin[4:5], normal[4:5], v, f, ns, lb, ub, res, clamp=0, accel=1, sampled_point=1)
+    assert t_1.sum() > 0 and rel_l2(row, t_1[0]) <= 1e-12 and np.array_equal(path1, p_1)
+    t_h, _ = orc.render_transient(origin[4:5], normal[4:5], v, f, ns, lb, ub, res, clamp=0, accel=1)
+    assert rel_l2(t_1, t_h) <= 1e-2                    # the streamed (hit-point) body: the same estimator up to bin-edge samples
     with pytest.raises(AssertionError, match="origin needs to be 1x3"):
         renderer_v1.renderTransient(np.zeros(2, np.float32), np.ascontiguousarray(normal[4]), v, f, ns, lb, ub, res, row, path1)
     with pytest.raises(AssertionError, match="transient dimension should match number of bins"):

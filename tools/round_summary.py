@@ -4,15 +4,20 @@ directory written by tools/profile_round.sh:  python tools/round_summary.py gpur
 
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB units; FETCH doubled: the gfx950 correction of
 MI355X_MICROARCH.md, calibrated on wide streaming reads -- an upper bound for this gathering kernel).
-issue block: valu_busy = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x launch duration x 2.4 GHz)  (a wave64 VALU
-instruction occupies its 16-lane SIMD for 4 cycles; 2.4 GHz = peak engine clock, so this is a lower bound),
-active_lane_frac = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU), lds_conflict_frac = SQ_LDS_BANK_CONFLICT /
-SQ_LDS_IDX_ACTIVE."""
+
+issue block (round 3): a WEIGHTED model instead of round 2's uniform "4 cycles per VALU instruction".  Issue costs per
+instruction class were measured on this chip (tools/issue_rate.hip -> profiles/r03_issue_rates.json: 2.3 cycles per wave64
+instruction per SIMD for v_add/mul/fma_f32, v_add_u32, v_and/xor, v_mov; 4.1 for compares, selects, min/max, shifts,
+integer multiplies, conversions, fp64, lane ops; 8.1 for v_sqrt/rcp/rsq_f32 -- the guide's "2 cycles" is right for the
+first class, round 2's "4" for the second), the class counts come from the SQ_INSTS_VALU_* counters of the same profile
+(tools/issue_model.py explains the bounds: INT32 and the unclassified rest mix both rates)."""
 import json
 import os
+import subprocess
 import sys
 
 root, L, F = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+here = os.path.dirname(os.path.abspath(__file__))
 pmc = json.load(open(os.path.join(root, "pmc_summary_all.json")))
 trace = json.load(open(os.path.join(root, "kernel_trace_summary.json")))
 
@@ -20,28 +25,51 @@ trace = json.load(open(os.path.join(root, "kernel_trace_summary.json")))
 def pick(d, prefix):
     c = [k for k in d if k.startswith(prefix) and not k.rstrip(">").endswith(", 1")]
     c.sort(key=lambda k: -d[k].get("SQ_INSTS_VALU", d[k].get("steady_mean_ms", 0)))
-    return d[c[0]] if c else None
+    return (c[0], d[c[0]]) if c else (None, None)
 
 
-fw, gr = pick(pmc, "k_forward_grid"), pick(pmc, "k_gradient")
-fw_t = pick(trace, "k_forward_grid")
+fw_name, fw = pick(pmc, "k_forward_grid")
+gr_name, gr = pick(pmc, "k_gradient")
+_, fw_t = pick(trace, "k_forward_grid")
+_, gr_t = pick(trace, "k_gradient")
 out = {"kernel": "k_forward", "L": L, "F": F,
        "hbm_bytes_per_launch": 1024.0 * (2 * fw["FETCH_SIZE"] + fw["WRITE_SIZE"]),
        "fetch_size_kb": fw["FETCH_SIZE"], "write_size_kb": fw["WRITE_SIZE"],
        "note": "steady-state means of the largest launches, rocprofv3 --pmc in separate passes (tools/profile_round.sh); "
                "FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md"}
+
+
+def model(name, ms):
+    """tools/issue_model.py on this profile's counters; the ISA text for the static split is optional"""
+    isa = os.environ.get("NLOS_ISA", os.path.join(root, "forward_grid.s"))
+    cmd = [sys.executable, os.path.join(here, "issue_model.py"), os.path.join(here, "..", "profiles", "r03_issue_rates.json"),
+           os.path.join(root, "pmc_summary_all.json"), name, "%.6f" % ms] + ([isa] if os.path.exists(isa) else [])
+    return json.loads(subprocess.check_output(cmd))
+
+
 dur_ms = fw_t["steady_mean_ms"] if fw_t else None
 if dur_ms:
     out["kernel_ms_under_trace"] = dur_ms
+    m = model(fw_name, dur_ms)
     out["issue"] = {
-        "valu_busy": fw["SQ_INSTS_VALU"] * 4.0 / (1024.0 * dur_ms * 1e-3 * 2.4e9),
+        "valu_busy": m["valu_busy"],
+        "mean_cycles_per_valu_inst": m["mean_cycles_per_valu_inst"],
+        "salu_busy": m["salu_busy"],
         "active_lane_frac": fw["SQ_THREAD_CYCLES_VALU"] / (64.0 * fw["SQ_ACTIVE_INST_VALU"]),
         "lds_conflict_frac": fw["SQ_LDS_BANK_CONFLICT"] / fw["SQ_LDS_IDX_ACTIVE"],
+        "wave_time_shares": {"parked_at_waitcnt_or_barrier": fw["SQ_WAIT_ANY"] / fw["SQ_WAVE_CYCLES"],
+                             "waiting_to_issue": fw.get("SQ_WAIT_INST_ANY", 0.0) / fw["SQ_WAVE_CYCLES"],
+                             "issuing": fw["SQ_ACTIVE_INST_ANY"] / fw["SQ_WAVE_CYCLES"]},
         "valu_insts_per_launch": fw["SQ_INSTS_VALU"], "salu_insts_per_launch": fw["SQ_INSTS_SALU"],
         "lds_insts_per_launch": fw["SQ_INSTS_LDS"], "vmem_insts_per_launch": fw["SQ_INSTS_VMEM"],
-        "basis": "SQ_* counters of k_forward_grid<0, 0, false, 0>, 1024 SIMDs, 4 cycles per wave64 VALU instruction, 2.4 GHz"}
+        "classes": m["classes"], "mixed_full_rate_fraction": m["mixed_full_rate_fraction"],
+        "basis": m["basis"] + "; kernel " + fw_name}
 if gr:
     out["k_gradient"] = {"hbm_bytes_per_launch": 1024.0 * (2 * gr["FETCH_SIZE"] + gr["WRITE_SIZE"]),
                          "valu_insts_per_launch": gr["SQ_INSTS_VALU"],
                          "active_lane_frac": gr["SQ_THREAD_CYCLES_VALU"] / (64.0 * gr["SQ_ACTIVE_INST_VALU"])}
+    if gr_t:
+        mg = model(gr_name, gr_t["steady_mean_ms"])
+        out["k_gradient"]["valu_busy"] = mg["valu_busy"]
+        out["k_gradient"]["kernel_ms_under_trace"] = gr_t["steady_mean_ms"]
 print(json.dumps(out, indent=1))
