@@ -184,7 +184,7 @@ def test_bounded_tile_scratch_renders_the_sources_in_chunks(tmp_path):
     assert str(a["backend"]) == "tiled-grid" and str(b["backend"]) == "tiled-grid"
     assert int(a["chunks"]) == 1 and int(b["chunks"]) >= 2
     assert a["t"].sum() > 0 and rel_l2(b["t"], a["t"]) <= 1e-12
-    assert rel_l2(b["g"], a["g"]) <= 1e-10
+    assert rel_l2(b["g"], a["g"]) <= 1e-6          # (two renders: see test_render_step_is_hip_graph_capturable)
 
 
 def test_device_path_surfaces_a_bad_face_index(bunny):

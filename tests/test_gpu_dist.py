@@ -50,7 +50,9 @@ def test_rccl_group_and_sharded_blocks(bunny):
         torch.cuda.synchronize()
         # fp64 atomics land in arrival order: repeat renders agree to rounding, not bit for bit
         assert rel_l2(t1.cpu().numpy(), t_ref.cpu().numpy()) < 1e-12
-        assert rel_l2(g1.cpu().numpy(), g_ref.cpu().numpy()) < 1e-12
+        # (gradient: to ~1e-8 -- the tap loop's (float)(-2 difference) amplifies the rows' last-bit noise at bins that sit
+        # on fp32 rounding midpoints, tests/test_gpu_rows.py::test_render_step_is_hip_graph_capturable)
+        assert rel_l2(g1.cpu().numpy(), g_ref.cpu().numpy()) < 1e-6
         assert sr.gather_transient(t1) is t1
 
         # what two ranks would compute, done in turn on this device, then summed as the all-reduce would
@@ -65,6 +67,6 @@ def test_rccl_group_and_sharded_blocks(bunny):
             rows.append(t.clone())
             acc += g
         assert rel_l2(torch.cat(rows).cpu().numpy(), t_ref.cpu().numpy()) < 1e-12   # rows depend on their own source only
-        assert rel_l2(acc.cpu().numpy(), g_ref.cpu().numpy()) < 1e-12   # fp64 summation order only
+        assert rel_l2(acc.cpu().numpy(), g_ref.cpu().numpy()) < 1e-6    # summation order, through the fp32 residual of the tap loop
     finally:
         dist.destroy_process_group()

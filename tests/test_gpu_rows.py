@@ -228,9 +228,11 @@ def test_device_tensor_path_sharding_and_autograd(bunny, orc):
                                     total_sources=9)
         rows.append(t)
         gsum += g
-    # rows depend on their own source only; fp64 atomics land in arrival order, so equal to rounding
+    # rows depend on their own source only; fp64 atomics land in arrival order, so equal to rounding (the gradient: to
+    # one fp32 ulp of the residual at the bins where the rows' last bit decides the (float) of the tap loop, see
+    # test_render_step_is_hip_graph_capturable)
     assert rel_l2(torch.cat(rows).cpu().numpy(), tr.cpu().numpy()) <= 1e-12
-    assert rel_l2(gsum.cpu().numpy(), grad.cpu().numpy()) <= 1e-12
+    assert rel_l2(gsum.cpu().numpy(), grad.cpu().numpy()) <= 1e-6
     # autograd: d/dv of sum(w * (data - T)^2) / L equals the reference-style gradient
     vp = tv.clone().requires_grad_(True)
     T_ = nd.render_transient_autograd(r, vp, to, tn, tf, ns, LB, UB, RES, refine_scale=10, sigma_bin=1)
@@ -724,9 +726,11 @@ def test_config4_shape_mannequin_nonconfocal_sharded(mannequin, orc):
                                     source_offset=lo, total_sources=16)
         rows.append(t)
         gsum += g
-    # rows depend on their own source only; fp64 atomics land in arrival order, so equal to rounding
+    # rows depend on their own source only; fp64 atomics land in arrival order, so equal to rounding (the gradient: to
+    # one fp32 ulp of the residual at the bins where the rows' last bit decides the (float) of the tap loop, see
+    # test_render_step_is_hip_graph_capturable)
     assert rel_l2(torch.cat(rows).cpu().numpy(), tr.cpu().numpy()) <= 1e-12
-    assert rel_l2(gsum.cpu().numpy(), grad.cpu().numpy()) <= 1e-12
+    assert rel_l2(gsum.cpu().numpy(), grad.cpu().numpy()) <= 1e-6
 
 
 def test_config5_shape_ggx_poisson_noised_1024_bins(bunny, orc):
@@ -838,7 +842,13 @@ def test_render_step_is_hip_graph_capturable(bunny):
         torch.cuda.synchronize()
     t2, g2, _ = r.render_gradient(to, tn, tv, tf_, 20000, LB, UB, RES, data=data, weight=w)
     assert (out["t"] - t2).abs().max().item() <= 1e-13 * t2.max().item()
-    assert rel_l2(grad.cpu().numpy(), g2.cpu().numpy()) <= 1e-9
+    # The gradient of two renders of the same scene agrees to ~1e-8, not to fp64 rounding: the tap loop multiplies by
+    # (float)(-2 * difference) as the reference does (smoothed_transient/transient_and_gradient.cpp:977-980), and that
+    # conversion turns the rows' summation-order noise (1e-16) into one fp32 ulp wherever 2 t sits on a rounding midpoint
+    # -- which sums of fp32 values scaled by 1 / spt = 1 / 5 do systematically (tools/determinism_probe.py: the visibility
+    # cache is bitwise equal, the rows differ in the last bit, a handful of bins flip their float).  Round 2 asserted
+    # 1e-9 here and failed about one run in ten.
+    assert rel_l2(grad.cpu().numpy(), g2.cpu().numpy()) <= 1e-6
     assert (t2 - t_ref).abs().max().item() > 0          # the replay really rendered the moved mesh
 
 
