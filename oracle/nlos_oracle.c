@@ -35,6 +35,18 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+/* threads > 0: that many OpenMP threads; 0: the host's default again (omp_set_num_threads is sticky: a caller that asked
+ * for one thread must not leave every later "default" call single-threaded -- the CPU suite ran 5x longer for that) */
+static void oracle_set_threads(int threads) {
+#ifdef _OPENMP
+    static int default_threads = 0;
+    if (default_threads == 0) default_threads = omp_get_max_threads();
+    omp_set_num_threads(threads > 0 ? threads : default_threads);
+#else
+    (void)threads;
+#endif
+}
+
 /* ------------------------------------------------------------------ vectors */
 typedef struct { float x, y, z; } v3;
 
@@ -326,7 +338,7 @@ int nlos_oracle_intersect(const float *origins, const float *dirs, int n_rays,
     scene_t sc;
     if (scene_init(&sc, V, nV, F, nF, accel)) return -1;
 #ifdef _OPENMP
-    if (threads > 0) omp_set_num_threads(threads);
+    oracle_set_threads(threads);
 #endif
     (void)threads;
 #pragma omp parallel for schedule(static)
@@ -599,7 +611,7 @@ static int forward_driver(const scene_t *sc, const float *origin, int L, const f
     memset(transient, 0, sizeof(double) * (size_t)L * (size_t)nbins);
     int nth = 1;
 #ifdef _OPENMP
-    if (op->threads > 0) omp_set_num_threads(op->threads);
+    oracle_set_threads(op->threads);
     nth = omp_get_max_threads();
 #endif
     /* per-thread private histograms like the reference (:301-316) */
@@ -816,7 +828,7 @@ static int gradient_driver(const scene_t *sc, const float *origin, int L, const 
     const int spt = 1 + ((num_samples - 1) / nF);
     int nth = 1;
 #ifdef _OPENMP
-    if (op->threads > 0) omp_set_num_threads(op->threads);
+    oracle_set_threads(op->threads);
     nth = omp_get_max_threads();
 #endif
     double *priv = (double *)calloc((size_t)nth * 3 * (size_t)nV, sizeof(double));
@@ -949,7 +961,7 @@ double nlos_oracle_render_gradient_scalar(const double *data, const double *weig
         const int spt = 1 + ((num_samples - 1) / nF);
         const long long ntask = (long long)L * nF;
 #ifdef _OPENMP
-        if (opts->threads > 0) omp_set_num_threads(opts->threads);
+        oracle_set_threads(opts->threads);
 #endif
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : total)
         for (long long idx = 0; idx < ntask; ++idx) {
@@ -979,7 +991,7 @@ int nlos_oracle_render_intensity(const float *origin, int L, const float *normal
     if (scene_init(&sc, V, nV, F, nF, opts->accel)) return -1;
     const int spt = 1 + ((num_samples - 1) / nF);
 #ifdef _OPENMP
-    if (opts->threads > 0) omp_set_num_threads(opts->threads);
+    oracle_set_threads(opts->threads);
 #endif
 #pragma omp parallel for schedule(dynamic, 16)
     for (int f = 0; f < nF; ++f) {
@@ -1312,7 +1324,7 @@ int nlos_oracle_render_jitter(const double *data, const double *weight,
     const int spt = 1 + ((num_samples - 1) / nF);
     if (pathlengths) fill_pathlengths(pathlengths, nbins, lb, res);
 #ifdef _OPENMP
-    if (opts->threads > 0) omp_set_num_threads(opts->threads);
+    oracle_set_threads(opts->threads);
 #endif
     jitter_forward(&sc, origin, L, normal, vnormal, albedo, num_samples, lb, ub, res, nbins,
                    jitter_weight, jitter_offset, jitter_length, transient, opts);
@@ -1536,7 +1548,7 @@ int nlos_oracle_render_nonconfocal(const double *data, const double *weight,
     if (pathlengths) fill_pathlengths(pathlengths, nbins, lb, res);
     memset(transient, 0, sizeof(double) * (size_t)P * (size_t)nbins);
 #ifdef _OPENMP
-    if (opts->threads > 0) omp_set_num_threads(opts->threads);
+    oracle_set_threads(opts->threads);
 #endif
     /* forward refinement rule of the v2 gradient driver (SMO/stratifiedStreamedGradientRenderer.cpp:521-524);
      * forward-only calls (data == NULL) refine whenever refine > 1, like renderStreamedTransient */

@@ -138,7 +138,7 @@ def test_grazing_rule_stays_inside_the_tolerance_of_the_rule_free_definition(orc
         data = t_con * (1.0 + 0.3 * rs.standard_normal(t_con.shape))
         weight = 0.5 + rs.random_sample(t_con.shape)
         t_con2, g_con, _ = orc.render_gradient(origin, normal, v, f, 20000, lb, ub, res, data, weight, seed=0, accel=1, **kw)
-        assert np.array_equal(t_con, t_con2)
+        assert rel_l2(t_con, t_con2) <= 1e-13          # (thread reduction order)
         with orc.rule_free():       # one call: rows and gradient of the rule-free all-faces definition
             t_free, g_free, _ = orc.render_gradient(origin, normal, v, f, 20000, lb, ub, res, data, weight, seed=0, accel=0, **kw)
         rows = np.linalg.norm(t_con - t_free, axis=1) / np.linalg.norm(t_free, axis=1)
