@@ -359,6 +359,8 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     const V3 ob = NCM == 2 ? ld3(a.src.sensor + 3 * (size_t)l) : o;
     const V3 onb = NCM == 2 ? ld3(a.src.sensor_normal + 3 * (size_t)l) : on;
     uint32_t* const visout = NCM == 1 ? a.vis2 : a.vis;
+    // item-mask layout of the visibility cache (launcher: single-workgroup grid, confocal; then a.vis == nullptr)
+    unsigned long long* const vitems = (!TILED && NCM == 0 && a.vis_items) ? a.vis_items + (size_t)l * (size_t)a.items_stride : nullptr;
 #ifdef NLOS_FWD_STAMPS
     // diagnostic build only: per-phase cycles summed over workgroups -> a.dbg[0..5]
     long long t_prev = clock64();
@@ -850,6 +852,14 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
         // with another item or tile) instead of storing it; ~0 = nothing pending.
         uint32_t pend_at = ~0u, pend_bits = 0u;
         uint32_t* const vrow = visout ? visout + (size_t)l * a.vis_words * F : nullptr;
+        // item-mask layout: the ballot of an item and its index are wave-uniform (scalar registers): one 8-byte store by
+        // lane 0, deferred like the words (behind the next item's loads)
+        int pend_item = -1;
+        unsigned long long pend_mask = 0ull;
+        auto flush_item = [&]() {
+            if (pend_item >= 0 && lane == 0) vitems[1 + pend_item] = pend_mask;
+            pend_item = -1;
+        };
         auto flush_pending = [&]() {
             if (pend_at != ~0u) {
                 uint32_t* wp = vrow + (pend_at & 0x7FFFFFFFu);
@@ -872,6 +882,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             Tri tr;
             load_face_tri<FEAT>(a.sc, jg, f, tr);
             if (visout) flush_pending();                                    // the previous item's words, behind this item's loads
+            if (vitems) flush_item();
             if (!compact && has_ray) has_ray = !face_dark(f);               // (the block masks are gone: the queue reuses their LDS)
             if (TILED && !compact && has_ray && frame_ok) {
                 // overflowed subset: every face is visited, most of them lie outside this tile
@@ -1101,9 +1112,11 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     else if (bits) { pend_at = at | 0x80000000u; pend_bits = bits << (s & 31); }
                 }
             }
+            if (vitems) { pend_item = b; pend_mask = __ballot(ok); }
             TACC(th);
         }
         if (visout) flush_pending();
+        if (vitems) flush_item();
     };
     if (use_grid) trace(std::true_type{});
     else trace(std::false_type{});
@@ -1128,6 +1141,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     // big-LDS launch only looks for the value 1
     // Every first-pass workgroup of the one-workgroup-per-source launch writes its code on its way out (0 = plain
     // grid), so the array needs no memset before the launch.
+    if (vitems && tid == 0) vitems[0] = (unsigned long long)n_live;      // pass 2 walks the live list (g_live stays valid)
     if (a.retry && tid == 0) {
         if (!TILED && pass == 0) a.retry[blockIdx.x] = COARSE ? 0x100 + R : (use_grid ? 0 : 0x200);
         else if (COARSE) a.retry[blockIdx.x] = 0x100 + R;
@@ -1164,7 +1178,14 @@ __global__ __launch_bounds__(kGridNT, kGridNT / 128) void k_forward_grid(Forward
 constexpr size_t kGridLdsBudget = 78 * 1024 - 128 - (kGridNT - 512) * 4;
 
 template <int FEAT, int NCM = 0>
-bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
+bool forward_grid_launch(const ForwardArgs& a_in, int rows_in_lds, hipStream_t stream) {
+    // visibility cache: item masks where this launch can record them (confocal; the live list is its index), per-face
+    // words otherwise -- never both
+    ForwardArgs b = a_in;
+    const bool items = NCM == 0 && b.vis_items && b.vis;
+    if (items) b.vis = nullptr;
+    else b.vis_items = nullptr;
+    const ForwardArgs& a = b;
     LaunchNote scratch_note;
     LaunchNote& note = tl_note ? *tl_note : scratch_note;
     if (a.force_bvh) { note.reason = 1; return false; }
@@ -1214,6 +1235,7 @@ bool forward_grid_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big), "hipFuncSetAttribute(k_forward_grid big-LDS)");
     note.backend = 1; note.reason = 0; note.grid_R = R; note.tiles = 1; note.tile_cap = 0;
     note.retry_workgroups = a.retry ? a.src.L : 0;
+    if (items) note.vis_items = 1;
     // kScan slots of slack: the walk reads kScan entries per trip and may touch the slots after the last list
     const int last_pass = a.retry ? 1 : 0;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, false, 0>), dim3(a.src.L), dim3(kGridNT), lds, stream, a, rows_in_lds, R,

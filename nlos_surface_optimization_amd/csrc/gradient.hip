@@ -13,6 +13,30 @@
 namespace nlos {
 namespace {
 
+// accepted-sample bits (spt <= 32) of live-list entry li out of the source's item masks: ray r = li * spt + s is bit r & 63
+// of item r >> 6 (items[0] = number of live faces, the masks follow)
+__device__ __forceinline__ uint32_t item_bits(const unsigned long long* __restrict__ items, int li, int spt) {
+    const uint32_t r0 = (uint32_t)li * (uint32_t)spt;
+    const uint32_t w = r0 >> 6, sh = r0 & 63u;
+    unsigned long long m = items[1 + w] >> sh;
+    if (sh + (uint32_t)spt > 64u) m |= items[2 + w] << (64u - sh);
+    return (uint32_t)(m & ((1ull << spt) - 1ull));
+}
+
+// item masks -> per-face words [L, 1, F] (spt <= 32), for the consumers that index the cache by face: the face-major
+// gradient kernel and the diagnostic read-back.  One workgroup per source.
+__global__ __launch_bounds__(256) void k_items_to_words(const unsigned long long* __restrict__ items, int items_stride,
+                                                        const uint16_t* __restrict__ live, int F, int spt,
+                                                        uint32_t* __restrict__ words) {
+    const int l = blockIdx.x;
+    uint32_t* w = words + (size_t)l * F;
+    for (int j = threadIdx.x; j < F; j += blockDim.x) w[j] = 0u;
+    __syncthreads();
+    const unsigned long long* it = items + (size_t)l * (size_t)items_stride;
+    const int n_live = (int)it[0];
+    for (int li = threadIdx.x; li < n_live; li += blockDim.x) w[live[(size_t)l * F + li]] = item_bits(it, li, spt);
+}
+
 #ifndef NLOS_GRAD_NT
 #define NLOS_GRAD_NT 512
 #define NLOS_GRAD_WPS 4
@@ -62,13 +86,22 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
             s_diff[i] = (MODE == 0 || MODE == 4) ? (double)(float)((-2) * d) : (-2) * d;      // scalar modes: -2 d in double
         }
         if (threadIdx.x == 0) *s_next = 0;
+        // Item-mask layout of the cache (nlos_kernels.h, ForwardArgs::vis_items): the entries to look at are those of the
+        // source's bucketed live list (half of the faces), their bits come out of one or two 64-bit item masks
+        const unsigned long long* it_l = a.vis_items ? a.vis_items + (size_t)l * (size_t)a.items_stride : nullptr;
+        const uint16_t* live_l = a.vis_items ? a.live + (size_t)l * F : nullptr;
+        const int n_src = it_l ? (int)it_l[0] : F;
         // faces with at least one accepted sample, compacted in order (pass 1 left the masks)
         for (int b = wave; b < nblocks; b += nwaves) {
             const int j = (b << 6) + lane;
             uint32_t any = 0;
-            if (j < F) {
-                const uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
-                for (int wi = 0; wi < a.vis_words; ++wi) any |= visp[(size_t)wi * F];
+            if (j < n_src) {
+                if (it_l) {
+                    any = item_bits(it_l, j, spt);
+                } else {
+                    const uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
+                    for (int wi = 0; wi < a.vis_words; ++wi) any |= visp[(size_t)wi * F];
+                }
             }
             const unsigned long long m = __ballot(any != 0u);
             if (lane == 0) s_mask[b] = m;
@@ -97,7 +130,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                 s_live[s_base[b] + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((b << 6) + lane);
         }
         __syncthreads();
-        const int n_live = a.compact ? (int)s_base[nblocks] : F;
+        const int n_live = a.compact ? (int)s_base[nblocks] : n_src;
         const int live_blocks = (n_live + 63) >> 6;
         const V3 o = ld3(a.src.origin + 3 * (size_t)l);
         const V3 on = ld3(a.src.normal + 3 * (size_t)l);
@@ -110,8 +143,11 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
             if (b >= live_blocks) break;
             const int li = (b << 6) + lane;
             if (li >= n_live) continue;
-            const int j = a.compact ? (int)s_live[li] : li;
-            const uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
+            const int e = a.compact ? (int)s_live[li] : li;          // a face slot, or (item masks) an entry of the live list
+            const int j = it_l ? (int)live_l[e] : e;
+            const uint32_t* visp = it_l ? nullptr : a.vis + ((size_t)l * a.vis_words) * F + j;
+            const uint32_t ibits = it_l ? item_bits(it_l, e, spt) : 0u;
+            const int n_words = it_l ? 1 : a.vis_words;
             Face f;
             Tri tr;
             load_face_tri<FEAT | FEAT_VN>(a.sc, j, f, tr);    // vertices, ids, and the per-face constants the scene build evaluated
@@ -122,8 +158,8 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
             for (int q = 0; q < 9; ++q) acc[q] = 0.0;
             double sacc = 0.0;
 
-            for (int wi = 0; wi < a.vis_words; ++wi) {
-                uint32_t word = visp[(size_t)wi * F];
+            for (int wi = 0; wi < n_words; ++wi) {
+                uint32_t word = it_l ? ibits : visp[(size_t)wi * F];
                 while (word) {
                     const int bit = __ffs(word) - 1;
                     word &= word - 1;
@@ -520,6 +556,12 @@ void gradient_launch(const GradientArgs& a, int grid, size_t lds, hipStream_t st
 
 }  // namespace
 
+void launch_items_to_words(const unsigned long long* items, int items_stride, const uint16_t* live, int L, int F, int spt,
+                           uint32_t* words, hipStream_t stream) {
+    if (L <= 0) return;
+    hipLaunchKernelGGL(k_items_to_words, dim3(L), dim3(256), 0, stream, items, items_stride, live, F, spt, words);
+}
+
 void launch_gradient(const GradientArgs& a_in, hipStream_t stream) {
     if (a_in.src.L <= 0) return;
     GradientArgs a = a_in;
@@ -533,6 +575,11 @@ void launch_gradient(const GradientArgs& a_in, hipStream_t stream) {
     a.lds_grad = ((a.mode == 0 || a.mode == 4) && a_in.lds_grad && lds + acc <= 150 * 1024) ? 1 : 0;
     if (!a.lds_grad && (a.mode == 0 || a.mode == 4) && a_in.lds_grad) {
         // large meshes: face-major variant (per-face sums in LDS across sources, one scatter per face)
+        if (a.vis_items && a.vis_scratch) {
+            // it indexes the cache by face: per-face words out of the item masks first
+            launch_items_to_words(a.vis_items, a.items_stride, a.live, a.src.L, a.sc.F, a.sp.spt, a.vis_scratch, stream);
+            a.vis = a.vis_scratch; a.vis_words = 1; a.vis_items = nullptr;
+        }
         bool done = false;
         switch (feat_of(a.sc, a.sp)) {
             case 0: done = gradient_fm_launch<0>(a, stream); break;

@@ -84,6 +84,11 @@ struct nlos_ctx {
     bool tree_complete = false;
     nlos::BuildArgs lazy_args;
     DevBuf lazy_flag;
+    // visibility cache as item masks (nlos_kernels.h, ForwardArgs::vis_items): what pass 1 of the single-workgroup grid
+    // records for confocal renders with spt <= 32; `vis_is_items` says which layout the cache of `vis_gen` is in
+    DevBuf vis_items;
+    bool vis_is_items = false;
+    int vis_items_stride = 0;
     // stale-cache protection: every scene build / recorded pass 1 takes the next value of one counter
     int64_t gen_counter = 0, mesh_gen = 0, vis_gen = 0;
     // what the last render did (nlos_ctx_last_path)
@@ -367,7 +372,7 @@ void nlos_ctx_destroy(nlos_ctx* c) {
     DeviceGuard g(c->device);
     DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                      &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag};
+                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag, &c->vis_items};
     for (DevBuf* b : all) b->release();
     for (DevBuf& b : c->io) b.release();
     for (hipEvent_t& e : c->ring) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
@@ -380,7 +385,7 @@ int64_t nlos_ctx_scratch_bytes(const nlos_ctx* c) {
     if (!c) return 0;
     const DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                            &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag};
+                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag, &c->vis_items};
     int64_t s = 0;
     for (const DevBuf* b : all) s += (int64_t)b->cap;
     for (const DevBuf& b : c->io) s += (int64_t)b.cap;
@@ -642,10 +647,21 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
               k.lb == key.lb && k.ub == key.ub && k.feat == key.feat))
             return fail(NLOS_ERR_ARG, "nlos_render: reuse_visibility requested but the cache does not match this render");
     }
+    fa.vis_items = nullptr; fa.items_stride = 0;
     if (two_pass || a->keep_visibility) {
         rc = c->vis.ensure(sizeof(uint32_t) * (size_t)L * vis_words * nF + 16);
         if (rc) return rc;
         fa.vis = c->vis.as<uint32_t>();
+        // item masks beside the words: the launcher that runs decides which of the two pass 1 records (the grid kernel
+        // of confocal renders takes the masks; pairs, tiled grid and BVH back-end keep the per-face words)
+        static const bool items_enabled = [] { const char* e = std::getenv("NLOS_VIS_ITEMS"); return !e || std::atoi(e) != 0; }();
+        if (items_enabled && !skip_pass1 && spt <= 32 && !a->sensor && fa.live && !fa.tile_list) {
+            const int stride = (int)(((size_t)nF * spt + 63) / 64) + 2;
+            rc = c->vis_items.ensure(sizeof(unsigned long long) * (size_t)L * stride + 16);
+            if (rc) return rc;
+            fa.vis_items = c->vis_items.as<unsigned long long>();
+            fa.items_stride = stride;
+        }
         c->vis_key = key;
         if (!skip_pass1) c->vis_gen = ++c->gen_counter;
     } else {
@@ -690,6 +706,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     c->path.rows_in_lds = note.rows_in_lds;
     c->path_retry_workgroups = note.retry_workgroups;
     if (note.tree_built) c->tree_complete = true;
+    if (!skip_pass1 && fa.vis) { c->vis_is_items = note.vis_items != 0; c->vis_items_stride = fa.items_stride; }
 #ifdef NLOS_FWD_STAMPS
     {
         long long h[24];
@@ -784,6 +801,10 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         ga.sc = sc; ga.src = src; ga.sp = sp;
         ga.sp.res = res; ga.sp.nbins = T;
         ga.vis = c->vis.as<uint32_t>(); ga.vis_words = vis_words;
+        ga.vis_items = c->vis_is_items ? c->vis_items.as<unsigned long long>() : nullptr;
+        ga.live = c->live.as<uint16_t>();
+        ga.items_stride = c->vis_items_stride;
+        ga.vis_scratch = c->vis.as<uint32_t>();
         ga.tap_w = c->taps.as<double>(); ga.tap_delta = ga.tap_w + K; ga.tap_g = ga.tap_w + 2 * K;
         ga.tap_p0 = ga.tap_w + 3 * K; ga.tap_p1 = ga.tap_w + 4 * K + 1; ga.tap_pw = ga.tap_w + 5 * K + 2;
         ga.K = K;
@@ -903,6 +924,12 @@ int64_t nlos_ctx_debug_read(nlos_ctx* c, int what, void* host_out, int64_t max_b
     if (n > (size_t)max_bytes) n = (size_t)max_bytes;
     if (n > b->cap) n = b->cap;
     hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess && what == 0 && c->vis_is_items) {
+        // the cache is held as item masks: per-face words for the reader
+        nlos::launch_items_to_words(c->vis_items.as<unsigned long long>(), c->vis_items_stride, c->live.as<uint16_t>(), c->vis_key.L,
+                                    c->vis_key.F, c->vis_key.spt, c->vis.as<uint32_t>(), nullptr);
+        e = hipDeviceSynchronize();
+    }
     if (e == hipSuccess) e = hipMemcpy(host_out, b->p, n, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return -(int64_t)fail(NLOS_ERR_HIP, std::string("nlos_ctx_debug_read: ") + hipGetErrorString(e));
     return (int64_t)n;
