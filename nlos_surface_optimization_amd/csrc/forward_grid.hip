@@ -825,7 +825,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     const uint64_t kbase0 = lg * (uint64_t)F;
     const double inv_spt = 1.0 / (double)spt;
 #ifdef NLOS_FWD_STAMPS
-    unsigned long long c_rays = 0, c_pairs = 0, c_iters = 0, c_mt = 0, c_mtw = 0;   // diagnostic build only
+    unsigned long long c_rays = 0, c_pairs = 0, c_iters = 0, c_mt = 0, c_mtw = 0, c_hit = 0, c_occ = 0, c_tested = 0;   // diagnostic build only
     long long tg = 0, ts = 0, tx = 0, th = 0, tmark = 0;
 #define TMARK() (tmark = clock64())
 #define TACC(v) do { long long now_ = clock64(); v += now_ - tmark; tmark = now_; } while (0)
@@ -857,7 +857,9 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
         int pend_item = -1;
         unsigned long long pend_mask = 0ull;
         auto flush_item = [&]() {
+#ifndef NLOS_DIAG_NO_ITEMSTORE     // diagnostic builds only: what the one store per item still costs
             if (pend_item >= 0 && lane == 0) vitems[1 + pend_item] = pend_mask;
+#endif
             pend_item = -1;
         };
         auto flush_pending = [&]() {
@@ -998,7 +1000,12 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                         if (qi < n) {
                             const int kg = gid(k);
                             const Tri tk = load_tri48(a.sc.tris, kg);
-                            if (tri_occludes(tk, o, od, ot, ofid, a.sc.face_id, kg, a.sc.tris))
+                            const bool hit_k = tri_occludes(tk, o, od, ot, ofid, a.sc.face_id, kg, a.sc.tris);
+#ifdef NLOS_FWD_STAMPS
+                            c_tested += 1;
+                            if (hit_k) c_hit += 1;
+#endif
+                            if (hit_k)
                                 atomicOr(&wocc[owner >> 5], 1u << (owner & 31));
                         }
                     }
@@ -1079,6 +1086,9 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 TACC(tx);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 if (grid_ray) ok = ((wocc[lane >> 5] >> (lane & 31)) & 1u) == 0u;
+#ifdef NLOS_FWD_STAMPS
+                if (grid_ray && !ok) c_occ += 1;
+#endif
                 __builtin_amdgcn_wave_barrier();
             } else {
                 TACC(tg);
@@ -1127,6 +1137,9 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
         atomicAdd((unsigned long long*)&a.dbg[10], c_iters);
         atomicAdd((unsigned long long*)&a.dbg[11], c_mt);
         atomicAdd((unsigned long long*)&a.dbg[12], c_mtw);
+        atomicAdd((unsigned long long*)&a.dbg[18], c_hit);
+        atomicAdd((unsigned long long*)&a.dbg[19], c_occ);
+        atomicAdd((unsigned long long*)&a.dbg[6], c_tested);
         if (tid == 0) atomicAdd((unsigned long long*)&a.dbg[13], (unsigned long long)s_ctl[2]);
         if (lane == 0) {
             atomicAdd((unsigned long long*)&a.dbg[14], (unsigned long long)tg);

@@ -723,6 +723,8 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         std::fprintf(stderr, "[fwd counters] rays %lld entries/source %.0f | scan: lane-it %.1f/ray, wave-it %.1f/ray-wave | queued %.2f/ray | exact rounds %.2f/ray-wave\n",
                      h[8], (double)h[13] / (double)(L > 0 ? L : 1), (double)h[9] / (double)(h[8] ? h[8] : 1), (double)h[10] / rw,
                      (double)h[11] / (double)(h[8] ? h[8] : 1), (double)h[12] / rw);
+        std::fprintf(stderr, "[fwd occlusion] rays found occluded %.1f%% | exact tests %lld, of which an occluder %.1f%%\n",
+                     100.0 * (double)h[19] / (double)(h[8] ? h[8] : 1), h[6], 100.0 * (double)h[18] / (double)(h[6] ? h[6] : 1));
         if (fa.tile_list)
             std::fprintf(stderr, "[fwd tiles] %d x %d tiles, capacity %d: %lld overflowing tiles, largest subset %lld | entry overflow: %lld workgroups, most entries %lld\n",
                          fa.tiles_x, fa.tiles_y, fa.tile_cap, h[22], h[23], h[20], h[21]);
