@@ -223,3 +223,77 @@ def test_device_path_surfaces_a_bad_face_index(bunny):
         r.timing_mean_ms()
     r.check()
     r.close()
+
+
+_ITEMS_SCRIPT = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from nlos_surface_optimization_amd import device as nd
+d = np.load(%r)
+v, f = d["v"], d["f"]
+g = np.linspace(-0.2, 0.2, 3)
+o = np.array([[x, y, 0] for y in g for x in g], np.float32)
+n = np.tile(np.array([0, 0, 1], np.float32), (9, 1))
+dev = torch.device("cuda", 0)
+r = nd.TransientRenderer(dev, seed=4)
+tv, tf, to, tn = (torch.from_numpy(x).to(dev) for x in (v, f, o, n))
+rs = np.random.RandomState(2)
+t, _ = r.render_transient(to, tn, tv, tf, 9000, 0.625, 1.625, 2.0 ** -9)
+data = torch.from_numpy(t.cpu().numpy() * (1 + 0.3 * rs.standard_normal(t.shape))).to(dev)
+t2, g2, _ = r.render_gradient(to, tn, tv, tf, 9000, 0.625, 1.625, 2.0 ** -9, data=data, weight=torch.ones_like(data))
+torch.cuda.synchronize()
+vis, fid = r.debug_visibility(9, 1 + (9000 - 1) // f.shape[0], f.shape[0])
+np.savez(sys.argv[1], t=t2.cpu().numpy(), g=g2.cpu().numpy(), vis=vis, fid=fid)
+"""
+
+
+def test_item_mask_visibility_equals_per_face_words(bunny, tmp_path):
+    """The visibility cache in its two layouts -- one 64-bit ballot per 64-ray item of the live list (what the grid kernel
+    records for confocal renders) and a word per (face, 32 strata) (NLOS_VIS_ITEMS=0: everywhere) -- describes the same
+    accepted samples: converted by k_items_to_words the caches are bitwise equal, and pass 2 gives the same gradient."""
+    import subprocess
+    import sys
+    golden = os.path.join(ROOT, "tests", "golden", "bunny_5k.npz")
+    outs = []
+    for items in ("1", "0"):
+        env = dict(os.environ)
+        env["NLOS_VIS_ITEMS"] = items
+        out = str(tmp_path / ("vis%s.npz" % items))
+        subprocess.run([sys.executable, "-c", _ITEMS_SCRIPT % (ROOT, golden), out], check=True, env=env, timeout=600)
+        outs.append(np.load(out))
+    a, b = outs
+    assert np.array_equal(a["fid"], b["fid"])
+    assert np.array_equal(a["vis"], b["vis"]) and int(np.unpackbits(a["vis"].view(np.uint8)).sum()) > 1000
+    assert rel_l2(a["t"], b["t"]) <= 1e-13 and rel_l2(a["g"], b["g"]) <= 1e-6
+
+
+def test_face_major_gradient_reads_an_item_mask_cache(orc):
+    """A mesh the single-workgroup grid renders (F <= 6.2 k) whose 3V-double accumulator does not fit LDS (a triangle soup:
+    V = 3 F): pass 1 records item masks, the face-major gradient kernel indexes the cache by face -- k_items_to_words sits
+    in between.  Against the oracle."""
+    import torch
+    from nlos_surface_optimization_amd import device as nd
+    rs = np.random.RandomState(12)
+    m = 3000
+    c = np.stack([rs.uniform(-0.25, 0.25, m), rs.uniform(-0.25, 0.25, m), rs.uniform(0.4, 0.6, m)], 1)
+    tri = c[:, None, :] + 0.02 * rs.normal(size=(m, 3, 3))
+    v = np.ascontiguousarray(tri.reshape(-1, 3), np.float32)
+    f = np.ascontiguousarray(np.arange(3 * m).reshape(m, 3), np.int32)
+    # wind every triangle towards the wall
+    p0, p1, p2 = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    flip = np.cross(p1 - p0, p2 - p0)[:, 2] > 0
+    f[flip] = f[flip][:, [0, 2, 1]]
+    o, n = grid_sources(3, 0.2)
+    ns = 4 * m
+    t_ref, _ = orc.render_transient(o, n, v, f, ns, LB, UB, RES, accel=1, seed=0)
+    data = np.ascontiguousarray(t_ref * (1 + 0.3 * rs.standard_normal(t_ref.shape)))
+    w = np.ones_like(data)
+    _, g_ref, _ = orc.render_gradient(o, n, v, f, ns, LB, UB, RES, data, w, accel=1, seed=0)
+    dev = torch.device("cuda", 0)
+    r = nd.TransientRenderer(dev, seed=0)
+    tv, tf, to, tn, td, tw = (torch.from_numpy(x).to(dev) for x in (v, f, o, n, data, w))
+    t, g, _ = r.render_gradient(to, tn, tv, tf, ns, LB, UB, RES, data=td, weight=tw)
+    p = r.last_path()
+    assert p["backend"] == "grid" and p["gradient_kernel"].startswith("face-major")
+    assert t_ref.sum() > 0 and rel_l2(t.cpu().numpy(), t_ref) <= 1e-5 and rel_l2(g.cpu().numpy(), g_ref) <= 1e-4
+    r.close()
