@@ -870,13 +870,23 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             }
             pend_at = ~0u;
         };
+#ifndef NLOS_SLOT_MAGIC
+#define NLOS_SLOT_MAGIC 1
+#endif
+        // ray -> (live-list slot, stratum): one v_mul_hi with M = ceil(2^32 / spt) where that is exact for every ray of
+        // this workgroup (r (M spt - 2^32) < 2^32: the error term then stays below 1 / spt), the generic division otherwise
+        const uint32_t spt_magic = spt > 1 ? 0xFFFFFFFFu / (uint32_t)spt + 1u : 0u;
+        const bool magic_ok = NLOS_SLOT_MAGIC && spt > 1 && (uint64_t)n_rays * (uint64_t)(uint32_t)(spt_magic * (uint32_t)spt) < (1ull << 32);
+        // (Claiming the next item and requesting its live-list entries one item ahead, so that ticket, entry and face
+        // records are not three dependent round trips in front of every item's arithmetic, changes nothing: the kernel
+        // waits for its VALU, not for these.  Measured, profiles/r03_ab_lookahead.log.)
         for (;;) {
             const int b = wave_ticket(&s_ctl[0]);
             if (b >= n_items) break;
             TMARK();
             const uint32_t r = ((uint32_t)b << 6) + (uint32_t)lane;
             bool has_ray = r < n_rays;
-            const uint32_t li = has_ray ? r / (uint32_t)spt : 0u;
+            const uint32_t li = has_ray ? (magic_ok ? __umulhi(r, spt_magic) : r / (uint32_t)spt) : 0u;
             const int s = has_ray ? (int)(r - li * (uint32_t)spt) : 0;
             const int j = compact ? (int)g_live[li] : (int)li;              // index within this workgroup's face set
             const int jg = gid(j);                                          // sorted-face index

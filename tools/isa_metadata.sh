@@ -2,7 +2,7 @@
 # ISA metadata of the hot kernels (runs where hipcc is: the build container cross-compiles gfx950):
 #   tools/isa_metadata.sh > profiles/rNN_isa_metadata.txt
 cd "$(dirname "$0")/.." || exit 1
-FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fno-fast-math -Wno-unused-function --offload-device-only -S"
+FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fno-fast-math -fno-slp-vectorize -Wno-unused-function --offload-device-only -S"
 T=$(mktemp -d)
 for f in forward_grid gradient bvh_build forward_bvh; do
   /opt/rocm/bin/hipcc $FLAGS nlos_surface_optimization_amd/csrc/$f.hip -o $T/$f.s 2>/dev/null

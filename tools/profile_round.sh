@@ -16,7 +16,7 @@ python3 tools/pmc_summary.py $OUT > $OUT/pmc_summary_all.json
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 python3 tools/trace_summary.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) > $OUT/kernel_trace_summary.json
 # the kernel's ISA text, for the static full-rate / half-rate split of the instruction classes the counters lump together
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fno-fast-math -Wno-unused-function --offload-device-only -S nlos_surface_optimization_amd/csrc/forward_grid.hip -o /tmp/nlos_forward_grid.s 2>/dev/null
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fno-fast-math -fno-slp-vectorize -Wno-unused-function --offload-device-only -S nlos_surface_optimization_amd/csrc/forward_grid.hip -o /tmp/nlos_forward_grid.s 2>/dev/null
 NLOS_ISA=/tmp/nlos_forward_grid.s python3 tools/round_summary.py $OUT 4096 4902 > $OUT/pmc_summary.json
 tail -1 $OUT/trace.log > $OUT/bench_line_under_profiler.json
 cat $OUT/kernel_stats.csv | cut -c1-200
