@@ -1035,7 +1035,11 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     if (m) {
                         // every lane stores -- the ones that append nothing into the dump slot: a select on the mask
                         // instead of a divergent region
+#ifdef NLOS_DIAG_MBCNT_ADD         // diagnostic builds only: the separate v_add_u32 this used to cost
                         const uint32_t at = (uint32_t)qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+#else
+                        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)qn));   // v_mbcnt adds its last operand: qn rides along
+#endif
                         uint32_t slot;
                         asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(slot) : "v"((uint32_t)kQueueCap), "v"(at), "s"(m));
                         wq[slot] = ((uint32_t)lane << 16) | (w & imask);

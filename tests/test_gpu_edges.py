@@ -56,6 +56,24 @@ def test_degenerate_and_duplicate_faces_contribute_like_the_oracle(bunny, orc):
     assert np.isfinite(grad).all() and rel_l2(grad, g_ref) <= 1e-4
 
 
+@pytest.mark.parametrize("spt", [701, 3000])
+def test_many_strata_per_face_both_ray_to_slot_divisions(bunny, orc, spt):
+    """The trace loop maps ray -> (live-list slot, stratum) with one multiply-high by ceil(2^32 / spt) where that is exact
+    for every ray of the workgroup and with the generic division otherwise (forward_grid.hip): spt = 701 on ~2 450 live
+    faces takes the first, spt = 3000 (rays x (M spt - 2^32) > 2^32) the second; 22 / 94 visibility words per face."""
+    v, f = bunny
+    o, n = grid_sources(1, 0.0)
+    o = o + np.float32([0.07, -0.05, 0.0])
+    ns = spt * f.shape[0]
+    t_ref, _ = orc.render_transient(o, n, v, f, ns, LB, UB, RES, accel=1)
+    tr, _, _ = _render(v, f, o, n, ns)
+    assert t_ref.sum() > 0 and rel_l2(tr, t_ref) <= 1e-12
+    d, w = t_ref * 0.7, np.ones_like(t_ref)
+    _, g_ref, _ = orc.render_gradient(o, n, v, f, ns, LB, UB, RES, d, w, accel=1)
+    _, grad, _ = _render(v, f, o, n, ns, data=d, weight=w)
+    assert rel_l2(grad, g_ref) <= 1e-4
+
+
 def test_temporal_kernel_longer_than_the_tap_limit_is_an_error(bunny):
     """4 * refine * sigma_bin + 1 taps are staged in LDS by the smoothing and gradient kernels: beyond 2048 the
     call is refused with a status (the reference would just allocate)."""
