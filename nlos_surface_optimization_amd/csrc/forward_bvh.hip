@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void k_forward(ForwardArgs a, int rows_in_lds)
                         inten += (double)val[c] / (double)spt;
                     } else if (bin[c] >= 0 && bin[c] < nbins) {
                         double cc = (double)val[c] / (double)spt;
-                        if (rows_in_lds) unsafeAtomicAdd(&s_row[bin[c]], cc);
+                        if (rows_in_lds) lds_add_f64(&s_row[bin[c]], cc);
                         else unsafeAtomicAdd(&grow[bin[c]], cc);
                     }
                 }
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void k_forward_nc(ForwardArgs a, int rows_in_l
             for (int c = 0; c < CH; ++c) {
                 if ((alive & (1u << c)) && bin[c] >= 0 && bin[c] < nbins) {
                     double cc = (double)val[c] / (double)spt;
-                    if (rows_in_lds) unsafeAtomicAdd(&s_row[bin[c]], cc);
+                    if (rows_in_lds) lds_add_f64(&s_row[bin[c]], cc);
                     else unsafeAtomicAdd(&grow[bin[c]], cc);
                 }
             }

@@ -1114,7 +1114,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 const double cc = (double)val * inv_spt;
                 if (a.mode_intensity) unsafeAtomicAdd(&a.intensity[fid], cc);
                 else if (bin >= 0 && bin < nbins) {
-                    if (rows_in_lds) unsafeAtomicAdd(&s_row[bin], cc);
+                    if (rows_in_lds) lds_add_f64(&s_row[bin], cc);
                     else unsafeAtomicAdd(&grow[bin], cc);
                 }
             }

@@ -112,6 +112,20 @@ __device__ __forceinline__ bool sample_geo(const Face& f, const Tri& tr, V3 o, u
 
 __device__ __forceinline__ float emax0(float x) { return 0.0f < x ? x : 0.0f; }
 
+// fp64 add into a row held in LDS, as ds_add_f64 whatever the optimiser thinks of the surrounding branches.  Written as
+// unsafeAtomicAdd(&s_row[bin], x) next to an unsafeAtomicAdd(&grow[bin], x) for the rows kept in HBM, the two calls are sunk
+// into ONE flat_atomic_add_f64 on a generic pointer (src_shared_base for the LDS case).  A FLAT operation counts in vmcnt
+// as well as lgkmcnt, which looked like the store stall of DESIGN.md 4.2 over again; measured, it is not (1.353 vs 1.349 ms,
+// profiles/r03_ab_flat.log) -- the LDS instruction is kept because it is what the code says.
+__device__ __forceinline__ void lds_add_f64(double* lds_ptr, double x) {
+#ifdef NLOS_DIAG_FLAT_ROW_ADD      // diagnostic builds only: the form the optimiser merges into a FLAT atomic
+    unsafeAtomicAdd(lds_ptr, x);
+#else
+    typedef __attribute__((address_space(3))) double lds_double;
+    __builtin_amdgcn_ds_atomic_fadd_f64((lds_double*)lds_ptr, x);
+#endif
+}
+
 __device__ __forceinline__ int wave_ticket(int* counter) {
     int b = 0;
     if ((threadIdx.x & 63) == 0) b = atomicAdd(counter, 1);
