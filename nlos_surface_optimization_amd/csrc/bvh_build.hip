@@ -5,7 +5,7 @@
 // rtcNewScene / RTC_BUILD_QUALITY_HIGH / rtcCommitScene every call).  The mesh
 // moves every optimisation step, so the build must be cheap and stay on the
 // device: one 1024-thread workgroup runs all phases back to back
-//   bounds -> 30-bit Morton keys -> LDS-counted radix sort (6 x 5 bit) ->
+//   bounds -> Morton keys (24 bits in the single-workgroup builder) -> stable LSD radix sort in LDS (4 x 6 bit, wave counters) ->
 //   Karras radix tree + escape links -> bottom-up box refit (in LDS while the inner nodes fit) + node emission
 // with workgroup barriers between phases (no host round trip, one launch,
 // graph-capturable).  Output is a stackless BVH: 32-byte nodes
@@ -376,6 +376,18 @@ __global__ __launch_bounds__(256) void k_build_refit(BuildArgs a, int conditiona
     }
 }
 
+// inclusive prefix sum over the 64 lanes of a wave on the DPP network (row shifts inside the rows of 16, then the two row
+// broadcasts of gfx9): six VALU operations instead of six ds_bpermute round trips
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);     // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);     // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);     // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);     // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+
 __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, int split) {
     extern __shared__ uint32_t s_dyn[];       // radix counters [RDIG * BT] (64 KB + skew), sort buffers; later the LDS refit
     __shared__ uint32_t s_wsum[BT / 64];
@@ -549,8 +561,119 @@ __global__ __launch_bounds__(1024) void k_build_bvh(BuildArgs a, int lds_words, 
             auto* ti = idx_in; idx_in = idx_out; idx_out = ti;
         }
     };
+    // The single-workgroup case proper (24-bit keys, keys and indices in LDS): 4 passes x 6 bits with one counter column
+    // per WAVE instead of one per thread -- 64 digits x 16 waves = one counter per thread for the scan, no private
+    // columns to zero, sum and rewrite.  Every wave owns a contiguous run of the input; within a 64-key round the rank of
+    // a key among the round's keys of the same digit comes from six ballots (match-any), so the scatter is stable by
+    // construction.  (Private columns: 6 passes x ~60 LDS operations per thread = 51 k cycles at F = 5 k; this: ~18 k.)
+    auto wave_sort = [&](uint32_t* keys_in, uint32_t* keys_out, uint16_t* idx_in, uint16_t* idx_out) {
+        constexpr int WBITS = 6, WDIG = 1 << WBITS, NW = BT / 64;
+        static_assert(WDIG * NW == BT, "one counter per thread");
+        static_assert(4 * WBITS == 3 * QBITS, "four passes cover the key");
+        const int per_wave = (F + NW - 1) / NW;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // scalar loop bounds
+        const int w0 = min(wave_u * per_wave, F), w1 = min(w0 + per_wave, F);
+        // (typed as LDS: a volatile access through a generic pointer is compiled to a system-coherent FLAT operation with a
+        // full wait behind it)
+        typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
+        lds_vu32* s_hist = (lds_vu32*)s_cnt;                         // [wave][digit]: a wave's 64 counters lie in 64 banks (digit-major,
+                                                                     // 16 words apart, they share four: 16-way conflicts, 4 k cycles per pass)
+#ifdef NLOS_BUILD_STAMPS
+        long long ts_prev = clock64(), ts_acc[3] = {0, 0, 0};     // summed in registers: a read-modify-write of the status words would stall the next phase
+#define NLOS_SUBSTAMP(k) do { long long t_now = clock64(); ts_acc[k] += t_now - ts_prev; ts_prev = t_now; } while (0)
+#else
+#define NLOS_SUBSTAMP(k) do { } while (0)
+#endif
+        constexpr int NR = KF;                                        // rounds of 64 keys per wave: per_wave <= KF * 64
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = pass * WBITS;
+            // the wave's keys and indices, once per pass and all in flight together; they feed the histogram AND the scatter
+            uint32_t k[NR], id[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int i = w0 + 64 * r + lane;
+                k[r] = i < w1 ? keys_in[i] : 0u;
+                id[r] = i < w1 ? (uint32_t)idx_in[i] : 0u;
+            }
+            // Ranks of all rounds first (ballots only): within a 64-key round, the lanes that hold my digit (match-any), my rank
+            // among them, and the group's first lane, which speaks for the group in both LDS phases -- the histogram takes one
+            // add of the group's size (sorted input puts whole rounds on one counter: 64 single adds serialise), and the
+            // scatter one returning add that claims the group's run.
+            uint32_t rank[NR], cnt[NR], dig[NR];
+            int leader[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                rank[r] = 1u; cnt[r] = 0u; leader[r] = 0; dig[r] = 0u;
+                if (w0 + 64 * r >= w1) continue;                    // (wave-uniform) no key in this round
+                const bool valid = w0 + 64 * r + lane < w1;
+                const uint32_t d = (k[r] >> shift) & (WDIG - 1);
+                // per digit bit one ballot and, per half of the mask, one three-input boolean: peers &= ~(ballot ^ (my bit ? ~0 : 0))
+                const unsigned long long vb = __ballot(valid);
+                uint32_t plo = (uint32_t)vb, phi = (uint32_t)(vb >> 32);
+#pragma unroll
+                for (int b = 0; b < WBITS; ++b) {
+                    const int sb = __builtin_amdgcn_sbfe((int)d, b, 1);      // 0 or -1
+                    const unsigned long long m = __ballot(sb != 0);
+                    plo &= ~((uint32_t)m ^ (uint32_t)sb);
+                    phi &= ~((uint32_t)(m >> 32) ^ (uint32_t)sb);
+                }
+                dig[r] = d;
+                cnt[r] = (uint32_t)(__popc(plo) + __popc(phi));
+                leader[r] = plo ? __ffs((int)plo) - 1 : (phi ? 31 + __ffs((int)phi) : 0);
+                rank[r] = valid ? __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u)) : 1u;    // 0: this lane speaks for its group
+            }
+            s_hist[tid] = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (rank[r] == 0u) atomicAdd(&s_cnt[wave_u * WDIG + dig[r]], cnt[r]);
+            __syncthreads();
+            NLOS_SUBSTAMP(0);                                       // loads + ranks + zero + histogram
+            // the scan runs digit-major (all waves' counts of digit 0, then digit 1 ...): thread t holds (digit t / 16, wave t % 16)
+            const int mine = (tid & (NW - 1)) * WDIG + (tid >> 4);
+            const uint32_t v = s_hist[mine];
+            const uint32_t incl = wave_incl_scan(v);
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            uint32_t wbase = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { const uint32_t x = s_wsum[w]; wbase += w < wave_u ? x : 0u; }   // 16 broadcast reads in flight, not a dependent chain
+            s_hist[mine] = wbase + incl - v;                        // exclusive: where the keys of (digit, wave) start
+            __syncthreads();
+            NLOS_SUBSTAMP(1);                                       // scan
+            // a wave's LDS operations execute in order, so round r + 1 sees what round r added without a wait in between;
+            // then every lane fetches its leader's base: three LDS round trips per pass instead of three per round
+            uint32_t at[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                at[r] = 0u;
+                if (rank[r] == 0u) at[r] = atomicAdd(&s_cnt[wave_u * WDIG + dig[r]], cnt[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) at[r] = __shfl(at[r], leader[r]);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                if (w0 + 64 * r + lane < w1) {
+                    keys_out[at[r] + rank[r]] = k[r];
+                    idx_out[at[r] + rank[r]] = (uint16_t)id[r];
+                }
+            }
+            __syncthreads();
+            NLOS_SUBSTAMP(2);                                       // ranks + scatter
+            uint32_t* tk = keys_in; keys_in = keys_out; keys_out = tk;
+            uint16_t* ti = idx_in; idx_in = idx_out; idx_out = ti;
+        }
+#ifdef NLOS_BUILD_STAMPS
+        if (tid == 0) for (int k = 0; k < 3; ++k) a.status[10 + k] = (int)ts_acc[k];
+#endif
+    };
     if (sort_in_lds) {
+#ifdef NLOS_DIAG_THREAD_SORT       // diagnostic builds only: the private-column sort for every size
         radix_sort(s_keyA, s_keyB, s_idxA, s_idxB);
+#else
+        if (in_regs) wave_sort(s_keyA, s_keyB, s_idxA, s_idxB);    // an even number of passes: the result is back in A
+        else radix_sort(s_keyA, s_keyB, s_idxA, s_idxB);
+#endif
         for (int f = tid; f < F; f += BT) { a.keys0[f] = s_keyA[f]; a.idx0[f] = (int)s_idxA[f]; }
         __syncthreads();
     } else {

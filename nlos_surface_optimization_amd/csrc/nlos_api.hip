@@ -295,7 +295,7 @@ int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bo
         int h[16];
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h, c->status.p, sizeof(h), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[build stamps] bounds %d morton %d sort %d karras %d refit %d (cycles)\n", h[4], h[5], h[6], h[7], h[8]);
+        std::fprintf(stderr, "[build stamps] bounds %d morton %d sort %d (histogram %d scan %d scatter %d) karras %d refit %d (cycles)\n", h[4], h[5], h[6], h[10], h[11], h[12], h[7], h[8]);
     }
 #endif
     c->built_F = nF; c->built_V = nV;

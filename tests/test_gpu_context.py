@@ -297,3 +297,49 @@ def test_face_major_gradient_reads_an_item_mask_cache(orc):
     assert p["backend"] == "grid" and p["gradient_kernel"].startswith("face-major")
     assert t_ref.sum() > 0 and rel_l2(t.cpu().numpy(), t_ref) <= 1e-5 and rel_l2(g.cpu().numpy(), g_ref) <= 1e-4
     r.close()
+
+
+def _morton_order(v, f):
+    """Host restatement of the single-workgroup builder's key (bvh_build.hip, phase 2: fp32 centroid sums, 8 bits per axis)
+    and the order a STABLE sort by it gives."""
+    def expand(x):
+        x = x.astype(np.uint64)
+        x = (x * 0x00010001) & 0xFF0000FF
+        x = (x * 0x00000101) & 0x0F00F00F
+        x = (x * 0x00000011) & 0xC30C30C3
+        x = (x * 0x00000005) & 0x49249249
+        return x
+    p = v[f]                                                        # [F, 3, 3] float32
+    lo, hi = p.reshape(-1, 3).min(0), p.reshape(-1, 3).max(0)
+    c = (np.float32(0) + p[:, 0]) + p[:, 1] + p[:, 2]
+    ext = hi - lo
+    inv = np.where(ext > 0, np.float32(1) / np.where(ext > 0, ext, np.float32(1)), np.float32(0)).astype(np.float32)
+    nrm = ((c * np.float32(1.0 / 3.0) - lo) * inv).astype(np.float32)
+    q = np.minimum(np.maximum(nrm * np.float32(256), np.float32(0)), np.float32(255)).astype(np.uint32)
+    key = (expand(q[:, 0]) << 2) | (expand(q[:, 1]) << 1) | expand(q[:, 2])
+    return key, np.argsort(key, kind="stable")
+
+
+@pytest.mark.parametrize("mesh", ["bunny", "mannequin", "ragged"])
+def test_scene_build_orders_the_faces_by_a_stable_morton_sort(bunny, mannequin, mesh):
+    """The face order every kernel works in (debug_read 1) is the stable sort of the 24-bit Morton keys of the fp32
+    centroid sums: the in-LDS radix sort of k_build_bvh (4 passes x 6 bits, one counter column per wave, ranks by
+    match-any ballots) against numpy's stable argsort -- on the benchmark mesh, on a mesh whose face count is no multiple
+    of anything (ragged last rounds of every wave), and with many equal keys (stability is what LSD radix relies on)."""
+    import torch
+    from nlos_surface_optimization_amd import device as nd
+    v, f = bunny if mesh != "mannequin" else mannequin
+    if mesh == "ragged":
+        f = np.ascontiguousarray(np.concatenate([f[:1237], f[:1237][::-1]]))       # 2 474 faces, every key twice
+    o, n = grid_sources(2, 0.2)
+    dev = torch.device("cuda", 0)
+    r = nd.TransientRenderer(dev)
+    tv, tf, to, tn = (torch.from_numpy(x).to(dev) for x in (v, f, o, n))
+    r.render_transient(to, tn, tv, tf, 2 * f.shape[0], 0.625, 1.625, 2.0 ** -9, keep_visibility=True)
+    torch.cuda.synchronize()
+    _, fid = r.debug_visibility(4, 2, f.shape[0])
+    key, order = _morton_order(v, f)
+    assert np.array_equal(np.sort(fid), np.arange(f.shape[0]))
+    assert (np.diff(key[fid].astype(np.int64)) >= 0).all()
+    assert np.array_equal(fid, order)
+    r.close()
