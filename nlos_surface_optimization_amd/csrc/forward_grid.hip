@@ -416,13 +416,6 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
         g.pady = kSubFrac + kSlopeAbs * (float)kSub * g.inv_ch;
     };
 
-    if (!TILED && NCM == 0 && a.res_diff && pass == 0 && blockIdx.x == 0) {
-        // fused residual: what k_residual does once per render (ResidualArgs::pathlengths, ::zero)
-        if (a.res_pathlengths)
-            for (int i = tid; i < a.sp.nbins; i += NT) a.res_pathlengths[i] = (double)(a.sp.lb + i * a.sp.res);
-        if (a.res_zero)
-            for (size_t i = tid; i < a.res_zero_n; i += NT) a.res_zero[i] = 0.0;
-    }
     if (!TILED && !frame_ok && a.need_tree && a.retry && pass < last_pass) {
         // lazy scene build: the tree does not exist yet.  This source (scene not strictly in front of its wall point)
         // needs the BVH query: flag it for the second launch, in front of which the tree is completed
@@ -1184,16 +1177,6 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
         __syncthreads();
         if (!TILED) {
             for (int i = tid; i < nbins; i += NT) grow[i] = s_row[i];
-            if (NCM == 0 && a.res_diff) {
-                // the residual of this source's row, the row still in LDS: render_kernels.hip k_residual, term for term
-                const size_t at = (size_t)l * (size_t)nbins;
-                for (int i = tid; i < nbins; i += NT) {
-                    double d = a.res_data[at + i] - s_row[i];
-                    if (a.res_loss_test == 1) d = 2 * d * d * d;
-                    if (a.res_weight) d = d * a.res_weight[at + i];
-                    a.res_diff[at + i] = d;
-                }
-            }
         } else {
             for (int i = tid; i < nbins; i += NT)
                 if (s_row[i] != 0.0) unsafeAtomicAdd(&grow[i], s_row[i]);     // one partial row per tile
@@ -1229,9 +1212,6 @@ bool forward_grid_launch(const ForwardArgs& a_in, int rows_in_lds, hipStream_t s
     const bool items = NCM == 0 && b.vis_items && b.vis;
     if (items) b.vis = nullptr;
     else b.vis_items = nullptr;
-    // fused residual: only where the workgroup of a source holds its final row (confocal, row in LDS)
-    const bool fuse = NCM == 0 && b.res_diff && rows_in_lds && b.rows && !b.mode_intensity;
-    if (!fuse) b.res_diff = nullptr;
     const ForwardArgs& a = b;
     LaunchNote scratch_note;
     LaunchNote& note = tl_note ? *tl_note : scratch_note;
@@ -1283,7 +1263,6 @@ bool forward_grid_launch(const ForwardArgs& a_in, int rows_in_lds, hipStream_t s
     note.backend = 1; note.reason = 0; note.grid_R = R; note.tiles = 1; note.tile_cap = 0;
     note.retry_workgroups = a.retry ? a.src.L : 0;
     if (items) note.vis_items = 1;
-    note.residual_fused = fuse ? 1 : 0;
     // kScan slots of slack: the walk reads kScan entries per trip and may touch the slots after the last list
     const int last_pass = a.retry ? 1 : 0;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, false, 0>), dim3(a.src.L), dim3(kGridNT), lds, stream, a, rows_in_lds, R,

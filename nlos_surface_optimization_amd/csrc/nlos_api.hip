@@ -567,8 +567,6 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.tile_list = nullptr;
     fa.tile_count = nullptr;
     fa.retry = nullptr;
-    fa.res_data = nullptr; fa.res_weight = nullptr; fa.res_diff = nullptr; fa.res_loss_test = 0;
-    fa.res_pathlengths = nullptr; fa.res_zero = nullptr; fa.res_zero_n = 0;
     fa.need_tree = c->tree_complete ? nullptr : c->lazy_flag.as<int>();
     fa.tiles_x = fa.tiles_y = fa.tile_cap = 0;
     static const int tile_threshold = [] { const char* e = std::getenv("NLOS_TILE_THRESHOLD"); return e ? std::atoi(e) : 6200; }();
@@ -690,30 +688,9 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
             fa.rows = transient;
         }
     }
-    // Residual fused into pass 1 (ForwardArgs::res_*): a plain gradient render whose rows are final as the forward kernel
-    // writes them.  Whether it happened is the launcher's word (note.residual_fused), chunk by chunk; if any chunk went
-    // another way the residual kernel below does the whole job as before.
-    static const bool fuse_enabled = [] { const char* e = std::getenv("NLOS_FUSE_RESIDUAL"); return !e || std::atoi(e) != 0; }();
-    const bool try_fuse = fuse_enabled && mode == NLOS_MODE_GRADIENT && needs_grad && !a->residual && !skip_pass1 && fwd_refine == 1 &&
-                          !jitter && !a->sensor && a->data && fa.rows == transient && transient;
-    bool all_fused = try_fuse;
-    if (try_fuse) {
-        rc = c->diff.ensure(sizeof(double) * (size_t)L * T + 16);
-        if (rc) return rc;
-        fa.res_data = a->data; fa.res_weight = a->weight; fa.res_diff = c->diff.as<double>(); fa.res_loss_test = a->loss_test;
-    }
     int n_chunks = 0;
     for (int l0 = 0; !skip_pass1 && l0 < L; l0 += chunk_L, ++n_chunks) {
         nlos::ForwardArgs fc = fa;
-        if (try_fuse) {
-            fc.res_data += (size_t)l0 * T; fc.res_diff += (size_t)l0 * T;
-            if (fc.res_weight) fc.res_weight += (size_t)l0 * T;
-            if (l0 == 0) {
-                fc.res_pathlengths = a->pathlengths;
-                if (a->zero_gradient) { fc.res_zero = a->gradient; fc.res_zero_n = 3 * (size_t)nV; }
-            }
-            note.residual_fused = 0;
-        }
         fc.src.L = L - l0 < chunk_L ? L - l0 : chunk_L;
         fc.src.origin += 3 * (size_t)l0; fc.src.normal += 3 * (size_t)l0;
         if (fc.src.sensor) { fc.src.sensor += 3 * (size_t)l0; fc.src.sensor_normal += 3 * (size_t)l0; }
@@ -723,9 +700,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         if (fc.vis2) fc.vis2 += (size_t)l0 * vis_words * nF;
         if (fc.tile_count) fc.retry = fc.tile_count + (size_t)fc.src.L * fc.tiles_x * fc.tiles_y;   // flags follow this chunk's subset sizes
         nlos::launch_forward(fc, st);
-        if (try_fuse && !note.residual_fused) all_fused = false;
     }
-    if (n_chunks == 0) all_fused = false;
     c->path.backend = note.backend; c->path.reason = note.reason; c->path.grid_R = note.grid_R;
     c->path.tiles = note.tiles; c->path.tile_cap = note.tile_cap; c->path.chunks = n_chunks;
     c->path.rows_in_lds = note.rows_in_lds;
@@ -800,10 +775,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         nlos::launch_residual(ra, st);
         zero_ptr = nullptr;
     }
-    if (needs_grad && !a->residual && all_fused) {
-        diff_ptr = c->diff.as<double>();        // written by the forward kernel, with the pathlengths and the cleared gradient
-        zero_ptr = nullptr;
-    } else if (needs_grad && !a->residual) {
+    if (needs_grad && !a->residual) {
         rc = c->diff.ensure(sizeof(double) * (size_t)L * T + 16);
         if (rc) return rc;
         nlos::ResidualArgs ra;

@@ -12,7 +12,6 @@ struct LaunchNote {
     int backend = 0, reason = 0, grid_R = 0, tiles = 0, tile_cap = 0, rows_in_lds = 0, gradient_kernel = 0;
     int retry_workgroups = 0;        // entries of the retry / path-code array the grid launches wrote
     int vis_items = 0;               // 1: pass 1 recorded the visibility cache as item masks (ForwardArgs::vis_items), not per-face words
-    int residual_fused = 0;          // 1: pass 1 wrote the residual, the pathlengths and the cleared gradient (ForwardArgs::res_*)
     // lazy scene build (grid back-end): the records exist, the tree does not yet.  The launchers complete it -- on a
     // device-side flag between the grid's two launches, unconditionally in front of a BVH back-end
     const struct BuildArgs* lazy_build = nullptr;
@@ -119,18 +118,6 @@ struct ForwardArgs {
     int* retry;              // [workgroups] flags of the big-LDS second launch (grid kernels) or null
     int* need_tree;          // lazy scene build: raised by first-launch workgroups that need the BVH query (they then leave it to
                              // the second launch, in front of which the tree is completed); null = the tree exists
-    // Residual fused into pass 1 (gradient renders whose rows are final when the workgroup of their source ends: the
-    // single-workgroup grid, confocal, rows in LDS): the workgroup writes diff = k_residual's arithmetic on its own row
-    // beside the row itself, workgroup 0 of the first launch writes the pathlengths and clears the gradient output --
-    // the step then holds no residual launch.  res_diff == nullptr: off.  LaunchNote::residual_fused reports whether
-    // the launcher that ran took it.
-    const double* res_data;      // [L, nbins]
-    const double* res_weight;    // [L, nbins] or null
-    double* res_diff;            // [L, nbins]
-    int res_loss_test;
-    double* res_pathlengths;     // [nbins] or null
-    double* res_zero;            // cleared (res_zero_n doubles) or null
-    size_t res_zero_n;
 };
 void launch_forward(const ForwardArgs& a, hipStream_t stream);
 // the two back-ends behind launch_forward (forward_grid.hip returns false when the BVH back-end is needed)

@@ -343,51 +343,3 @@ def test_scene_build_orders_the_faces_by_a_stable_morton_sort(bunny, mannequin, 
     assert (np.diff(key[fid].astype(np.int64)) >= 0).all()
     assert np.array_equal(fid, order)
     r.close()
-
-
-_FUSE_SCRIPT = """
-import sys, numpy as np, torch
-sys.path.insert(0, %r)
-from nlos_surface_optimization_amd import device as nd
-d = np.load(%r)
-v, f = d["v"], d["f"]
-g = np.linspace(-0.2, 0.2, 3)
-o = np.array([[x, y, 0] for y in g for x in g], np.float32)
-n = np.tile(np.array([0, 0, 1], np.float32), (9, 1))
-dev = torch.device("cuda", 0)
-r = nd.TransientRenderer(dev, seed=4)
-tv, tf, to, tn = (torch.from_numpy(x).to(dev) for x in (v, f, o, n))
-rs = np.random.RandomState(2)
-t, _ = r.render_transient(to, tn, tv, tf, 20000, 0.625, 1.625, 2.0 ** -9)
-data = torch.from_numpy(t.cpu().numpy() * (1 + 0.3 * rs.standard_normal(t.shape))).to(dev)
-w = torch.from_numpy(0.5 + rs.random_sample(t.shape)).to(dev)
-out = {}
-for tag, kw in (("plain", {}), ("cubic", {"loss_flag": 1})):
-    grad = torch.full((v.shape[0], 3), 7.0, dtype=torch.float64, device=dev)      # must be cleared by the render
-    t2, g2, p2 = r.render_gradient(to, tn, tv, tf, 20000, 0.625, 1.625, 2.0 ** -9, data=data, weight=w, gradient=grad,
-                                   zero_gradient=True, **kw)
-    torch.cuda.synchronize()
-    out["t_" + tag], out["g_" + tag], out["p_" + tag] = t2.cpu().numpy(), g2.cpu().numpy(), p2.cpu().numpy()
-np.savez(sys.argv[1], **out)
-"""
-
-
-def test_residual_fused_into_pass_1_equals_the_residual_kernel(bunny, tmp_path):
-    """Plain gradient renders on the single-workgroup grid write the residual, the pathlengths and the cleared gradient from
-    the forward kernel (ForwardArgs::res_*; no k_residual launch in the step).  NLOS_FUSE_RESIDUAL=0 keeps the separate
-    kernel: rows, pathlengths and gradient agree (the gradient to the run-to-run spread of its fp32 residual products),
-    with and without the cubic test loss, with a weight, into a gradient buffer that held garbage."""
-    golden = os.path.join(ROOT, "tests", "golden", "bunny_5k.npz")
-    outs = []
-    for fuse in ("1", "0"):
-        env = dict(os.environ)
-        env["NLOS_FUSE_RESIDUAL"] = fuse
-        out = str(tmp_path / ("fuse%s.npz" % fuse))
-        subprocess.run([sys.executable, "-c", _FUSE_SCRIPT % (ROOT, golden), out], check=True, env=env, timeout=600)
-        outs.append(np.load(out))
-    a, b = outs
-    for tag in ("plain", "cubic"):
-        assert rel_l2(a["t_" + tag], b["t_" + tag]) <= 1e-14
-        assert np.array_equal(a["p_" + tag], b["p_" + tag])
-        assert np.abs(b["g_" + tag]).max() > 0 and rel_l2(a["g_" + tag], b["g_" + tag]) <= 1e-6
-    assert rel_l2(a["g_plain"], a["g_cubic"]) > 1e-3
