@@ -14,7 +14,8 @@ for k, v in d.items():
     if "VALU" not in str(v) or v.get("SQ_INSTS_VALU", 0) < 1e6:
         continue
     lanes = v.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * max(v.get("SQ_ACTIVE_INST_VALU", 1), 1))
-    print("%-40s VALU %.4g SALU %.4g LDS %.4g VMEM %.4g | lanes %.3f | LDS conflict %.3f | wave-cycles %.4g" % (
+    print("%-40s VALU %.4g SALU %.4g LDS %.4g VMEM %.4g | lanes %.3f | LDS conflict %.3f (%.4g of %.4g LDS cycles) | wave-cycles %.4g" % (
         k[:40], v.get("SQ_INSTS_VALU", 0), v.get("SQ_INSTS_SALU", 0), v.get("SQ_INSTS_LDS", 0), v.get("SQ_INSTS_VMEM", 0), lanes,
-        v.get("SQ_LDS_BANK_CONFLICT", 0) / max(v.get("SQ_LDS_IDX_ACTIVE", 1), 1), v.get("SQ_WAVE_CYCLES", 0)))
+        v.get("SQ_LDS_BANK_CONFLICT", 0) / max(v.get("SQ_LDS_IDX_ACTIVE", 1), 1), v.get("SQ_LDS_BANK_CONFLICT", 0),
+        v.get("SQ_LDS_IDX_ACTIVE", 0), v.get("SQ_WAVE_CYCLES", 0)))
 PY
