@@ -160,7 +160,7 @@ __device__ __forceinline__ uint32_t make_entry(const GridView& g, const BBoxF& b
 // for the rounding of the projection.  (Round 1 re-evaluated the three edge functions from the cell coordinates
 // in every cell: 30 VALU operations per cell against 7 here, and the build phases were 41 % of the kernel.)
 struct RasterAll { __device__ __forceinline__ bool operator()(int, int, int, int) const { return true; } };
-template <class Fn, class Pre = RasterAll>
+template <bool BBOX = false, class Fn, class Pre = RasterAll>
 __device__ __forceinline__ void raster_cells(float gx0, float gy0, float inv_cw, float inv_ch, int Rx, const Proj2& q, float ms, Fn fn,
                                              Pre pre = Pre()) {
     const float cw = __builtin_amdgcn_rcpf(inv_cw), ch = __builtin_amdgcn_rcpf(inv_ch);
@@ -171,6 +171,11 @@ __device__ __forceinline__ void raster_cells(float gx0, float gy0, float inv_cw,
     const int cy0 = cell_coord(fminf(fminf(q.ay, q.by), q.cy) - mgy, gy0, inv_ch, Rx);
     const int cy1 = cell_coord(fmaxf(fmaxf(q.ay, q.by), q.cy) + mgy, gy0, inv_ch, Rx);
     if (!pre(cx0, cx1, cy0, cy1)) return;
+    if (BBOX) {                     // bounding box only (conservative superset of the cells the triangle enters)
+        for (int yy = cy0; yy <= cy1; ++yy)
+            for (int xx = cx0; xx <= cx1; ++xx) fn(xx, yy);
+        return;
+    }
     // edge functions, oriented so that the inside is >= 0
     const float area = (q.bx - q.ax) * (q.cy - q.ay) - (q.by - q.ay) * (q.cx - q.ax);
     const float sgn = area < 0.0f ? -1.0f : 1.0f;
@@ -215,7 +220,14 @@ template <class Fn>
 __device__ __forceinline__ void raster_tri_coarse(const GridView& g, int R2, const Proj2& q, Fn fn) {
     // (the rays towards a LIVE face end inside its projection up to rounding: base margins; what scales with the
     // face's grazing angle is the depth its own hits are reported at, see zb at the call sites)
+    // From the bounding box alone (round 3): a coarse cell is 2 x 2 cells and a triangle about one, so its box covers
+    // little more than the triangle does, and a depth bound may only be too LARGE (it culls less, never wrongly); the
+    // edge functions cost the pass half of its instructions.  Forward 1.358 -> 1.341 ms (profiles/r03_ab_zc_bbox.log).
+#ifdef NLOS_DIAG_ZC_EDGES          // diagnostic builds only: the exact coverage
     raster_cells(g.gx0, g.gy0, 0.5f * g.inv_cw, 0.5f * g.inv_ch, R2, q, 1.0f, fn);
+#else
+    raster_cells<true>(g.gx0, g.gy0, 0.5f * g.inv_cw, 0.5f * g.inv_ch, R2, q, 1.0f, fn);
+#endif
 }
 
 // Slope-space frame of a source: bounding rectangle of the projection of the BVH's (padded) root box.
