@@ -69,6 +69,22 @@ def load_pmc_summary():
         return None
 
 
+def counters_of_this_build(pmc, kernel, comparable, L, F):
+    """(hbm bytes per launch or None, issue block or {"stale": ...} or None, stamp of this build, stamp of the profile).
+    Counters are reported only from a profile of THIS build: profiles/pmc_summary.json carries the hash of the kernel
+    sources it was taken on (tools/round_summary.py, _lib.source_stamp); a summary of other sources -- or one without
+    a stamp -- gives traffic None and issue {"stale": ...}, never another binary's numbers."""
+    from nlos_surface_optimization_amd import _lib
+    here = _lib.source_stamp()
+    if not (pmc and comparable and pmc.get("kernel") == kernel and pmc.get("L") == L and pmc.get("F") == F):
+        return None, None, here, None
+    stamp = pmc.get("stamp") or {}
+    if stamp.get("source_sha256_16") != here["source_sha256_16"]:
+        return None, {"stale": "profiles/pmc_summary.json was taken on kernel sources %s, this build is %s: counters not reported"
+                               % (stamp.get("source_sha256_16"), here["source_sha256_16"])}, here, stamp
+    return pmc.get("hbm_bytes_per_launch"), pmc.get("issue"), here, stamp
+
+
 # ------------------------------------------------------------------------------------------------
 # CPU side of rank 0: the oracle as parity checker and as the reported baseline (never the product)
 # ------------------------------------------------------------------------------------------------
@@ -540,9 +556,7 @@ def run_rank(args, backend):
         local_samples = L * F * spt
         if kt[dom] > 0 and per_sample > 0:
             achieved = per_sample * local_samples / (kt[dom] * 1e-3) / 1e9
-            pmc = load_pmc_summary()
-            same = bool(pmc) and plain and world == 1 and pmc.get("kernel") == names[dom] and pmc.get("L") == L and pmc.get("F") == F
-            traffic = pmc.get("hbm_bytes_per_launch") if same else None
+            traffic, issue, here_stamp, pmc_stamp = counters_of_this_build(load_pmc_summary(), names[dom], plain and world == 1, L, F)
             roof = {
                 # the contract's figure: ALGORITHMIC bytes of SURVEY 8(d) per launch / measured kernel time, against
                 # HBM peak.  It is a model of the reference's traffic, not this kernel's: rows, grid and accumulators
@@ -556,9 +570,13 @@ def run_rank(args, backend):
             if traffic:
                 roof["hbm_measured_GBps"] = traffic / (kt[dom] * 1e-3) / 1e9
                 roof["hbm_measured_frac"] = roof["hbm_measured_GBps"] / HBM_PEAK_GBS
-            if same and pmc.get("issue"):
-                # the ceiling that binds: VALU issue slots (from the committed PMC passes of this same command)
-                roof["issue"] = pmc["issue"]
+            roof["build"] = here_stamp
+            if issue:
+                # the ceiling that binds: VALU issue slots (from the committed PMC passes of this same command on this
+                # same build), or {"stale": ...} when the committed counters belong to other kernel sources
+                roof["issue"] = issue
+            if traffic:
+                roof["profile_stamp"] = pmc_stamp
             out["roofline"] = roof
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base

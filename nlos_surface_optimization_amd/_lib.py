@@ -179,6 +179,28 @@ def build(force=False):
     return LIB_PATH
 
 
+def source_stamp():
+    """Identity of the kernels a measurement belongs to: sha256 over the sources libnlos_hip.so is built from
+    (csrc/*.hip, csrc/*.h, csrc/Makefile, include/*.h; file names and contents, sorted), first 16 hex digits, plus the
+    same of the built library.  The SOURCE hash is what a profile is matched on: two builds of the same sources in
+    different directories differ in a few hundred bytes (embedded paths), so the library hash is informative only.
+    Used by tools/round_summary.py (stamps profiles/pmc_summary.json) and bench.py (refuses counters of another build)."""
+    import hashlib
+    h = hashlib.sha256()
+    inc = os.path.join(_HERE, "..", "include")
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) or f == "Makefile"]
+    files += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
+    for f in sorted(files, key=os.path.basename):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    out = {"source_sha256_16": h.hexdigest()[:16], "lib_sha256_16": None}
+    if os.path.exists(LIB_PATH):
+        with open(LIB_PATH, "rb") as fh:
+            out["lib_sha256_16"] = hashlib.sha256(fh.read()).hexdigest()[:16]
+    return out
+
+
 def _preload_hip_runtime():
     """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64.so
     (SONAME libamdhip64.so.7, loaded by file name through RPATH $ORIGIN), while libnlos_hip.so

@@ -377,6 +377,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     // diagnostic build only: per-phase cycles summed over workgroups -> a.dbg[0..5]
     long long t_prev = clock64();
     int t_slot = 0;
+    const long long c_start = t_prev, w_start = wall_clock64();   // shader-clock ticks vs the constant 100 MHz counter -> a.dbg[24], [25]
 #define FWD_STAMP() do { __syncthreads(); if (tid == 0 && a.dbg) { long long t_now = clock64(); atomicAdd((unsigned long long*)&a.dbg[t_slot], (unsigned long long)(t_now - t_prev)); ++t_slot; t_prev = t_now; } } while (0)
 #else
 #define FWD_STAMP() do { } while (0)
@@ -597,44 +598,10 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             // ---- counting pass -----------------------------------------------------------------------
             int pend_jl = -1;
             uint16_t pend_cov = 0;
-            // NLOS_COUNT_COMPACT (written at the end of round 3, compiled, NOT yet measured: DESIGN.md section 8): about half of
-            // the triangles leave the pass at its reach test, and where Morton order does not cluster them their lanes idle
-            // while the neighbours rasterise (59 % active lanes in the build phases).  A pre-pass applies the reach test to
-            // every triangle and appends the survivors to a list in the entry area (free until the fill pass); the pass
-            // proper then runs over that list on dense lanes.  Cell counts and coverage words do not depend on the order.
-#ifdef NLOS_COUNT_COMPACT
-            const bool compact_count = Fl <= cap;
-            int n_count = Fl;
-            if (compact_count) {
-                if (tid == 0) s_ctl[5] = 0;
-                __syncthreads();
-                for (int base = wave * 64; base < Fl; base += NT) {          // wave-uniform trip count: the ballot below sees every lane
-                    const int jl = base + lane;
-                    bool reach = false;
-                    if (jl < Fl) {
-                        const int j = gid(jl);
-                        const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
-                        const float ms = (float)g_live[jl] * (1.0f / 64.0f);
-                        const Proj2 q = project_tri(o, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x));
-                        const uint32_t zn = __float_as_uint(fmaxf(fminf(fminf(q0.z, q1.y), q2.x) - o.z, 0.0f) * (1.0f - kDepthEps * ms));
-                        raster_tri(g, q, ms, [&](int, int) {}, [&](int cx0, int cx1, int cy0, int cy1) -> bool {
-                            reach = reachable(zn)(cx0, cx1, cy0, cy1);
-                            return false;                                     // the bounding box and the reach test only
-                        });
-                        if (!reach) g_cov[jl] = 0;
-                    }
-                    const unsigned long long m = __ballot(reach);
-                    uint32_t at = 0u;
-                    if (lane == 0 && m) at = atomicAdd(reinterpret_cast<uint32_t*>(&s_ctl[5]), (uint32_t)__popcll(m));
-                    at = __shfl(at, 0);
-                    if (reach) s_ent[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)jl;
-                }
-                __syncthreads();
-                n_count = s_ctl[5];
-            }
-            for (int it = tid; it < n_count; it += NT) {
-                const int jl = compact_count ? (int)s_ent[it] : it;
-#elif defined(NLOS_DIAG_NO_COUNT)  // diagnostic builds only (tools/ab_pmc.sh)
+            // (Round 4, measured and removed: a pre-pass that applies the reach test to every triangle and compacts the
+            // survivors so that the pass proper runs on dense lanes -- the pre-pass repeats projection, bounding box and
+            // reach test, and costs more than the idle lanes did: forward 1.334 -> 1.433 ms, profiles/r04_ab_count_compact.log.)
+#if defined(NLOS_DIAG_NO_COUNT)    // diagnostic builds only (tools/ab_pmc.sh)
             for (int jl = Fl; jl < Fl; jl += NT) {
 #else
             for (int jl = tid; jl < Fl; jl += NT) {
@@ -1213,6 +1180,12 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     }
 #endif
     FWD_STAMP();   // 5: sample + trace + histogram
+#ifdef NLOS_FWD_STAMPS
+    if (tid == 0 && a.dbg) {   // the shader clock this kernel really ran at: sum of s_memtime ticks / sum of s_memrealtime ticks (100 MHz)
+        atomicAdd((unsigned long long*)&a.dbg[24], (unsigned long long)(clock64() - c_start));
+        atomicAdd((unsigned long long*)&a.dbg[25], (unsigned long long)(wall_clock64() - w_start));
+    }
+#endif
     // diagnostics (nlos_ctx_debug_read what = 2): the coarsened resolution this workgroup ended up with; the
     // big-LDS launch only looks for the value 1
     // Every first-pass workgroup of the one-workgroup-per-source launch writes its code on its way out (0 = plain

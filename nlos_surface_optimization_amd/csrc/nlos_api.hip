@@ -709,7 +709,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     if (!skip_pass1 && fa.vis) { c->vis_is_items = note.vis_items != 0; c->vis_items_stride = fa.items_stride; }
 #ifdef NLOS_FWD_STAMPS
     {
-        long long h[24];
+        long long h[26];
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h, c->status.p, sizeof(h), hipMemcpyDeviceToHost));
         double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5]);
@@ -725,6 +725,19 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
                      (double)h[11] / (double)(h[8] ? h[8] : 1), (double)h[12] / rw);
         std::fprintf(stderr, "[fwd occlusion] rays found occluded %.1f%% | exact tests %lld, of which an occluder %.1f%%\n",
                      100.0 * (double)h[19] / (double)(h[8] ? h[8] : 1), h[6], 100.0 * (double)h[18] / (double)(h[6] ? h[6] : 1));
+        if (h[25] > 0) {
+            // s_memtime counts shader-clock cycles, s_memrealtime the constant 100 MHz reference: their ratio over the
+            // workgroups' lifetimes is the engine clock the forward kernel ran at (tools/issue_model.py uses it)
+            const double ghz = 0.1 * (double)h[24] / (double)h[25];
+            std::fprintf(stderr, "[fwd clock] %.4f GHz over %d sources\n", ghz, L);
+            if (const char* cj = std::getenv("NLOS_CLOCK_JSON")) {
+                if (FILE* fj = std::fopen(cj, "w")) {
+                    std::fprintf(fj, "{\"clock_ghz\": %.5f, \"sources\": %d, \"basis\": \"sum of s_memtime ticks / sum of s_memrealtime ticks (100 MHz) over the "
+                                     "workgroups of k_forward_grid, -DNLOS_FWD_STAMPS build\"}\n", ghz, L);
+                    std::fclose(fj);
+                }
+            }
+        }
         if (fa.tile_list)
             std::fprintf(stderr, "[fwd tiles] %d x %d tiles, capacity %d: %lld overflowing tiles, largest subset %lld | entry overflow: %lld workgroups, most entries %lld\n",
                          fa.tiles_x, fa.tiles_y, fa.tile_cap, h[22], h[23], h[20], h[21]);

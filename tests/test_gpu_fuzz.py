@@ -13,7 +13,12 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 @pytest.mark.gpu
 def test_random_scenes_match_the_oracle():
+    # seed 7: cases 1 and 7 of the first 16 are many-source scenes (397 and 76 sources)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "16", "7"],
-                         capture_output=True, text=True, timeout=900)
-    tail = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-400:]
+                         capture_output=True, text=True, timeout=1500)
+    lines = out.stdout.strip().splitlines()
+    tail = lines[-1] if lines else out.stderr[-400:]
     assert out.returncode == 0 and "mismatches 0 / 16" in tail, out.stdout[-3000:] + out.stderr[-1000:]
+    # not one sample may differ (the rows gate is 1e-12), in logged cases and in the empty draws alike
+    assert any(ln.startswith("cases with a differing sample") and ln.rstrip().endswith(": 0") for ln in lines), out.stdout[-3000:]
+    assert sum(ln.startswith("case ") and "sum=0.000e+00" not in ln for ln in lines) >= 16, out.stdout[-3000:]

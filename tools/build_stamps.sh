@@ -1,5 +1,7 @@
 #!/bin/bash
-# diagnostic: per-phase cycles of k_build_bvh. Builds a stamped copy of the library in /tmp, never the shipped one.
+# diagnostic: per-phase cycles of k_build_bvh and k_forward_grid, work counters, and the shader clock the forward kernel runs at
+# (NLOS_CLOCK_JSON=<file>: written as JSON; NLOS_STAMP_GRID=64 NLOS_STAMP_NS=20000: the metric workload).
+# Builds a stamped copy of the library in /tmp, never the shipped one.
 set -e
 cd "$GRAFT_REPO_ROOT"
 cp -r nlos_surface_optimization_amd /tmp/nlos_stamped && cp -r include /tmp/include
@@ -21,8 +23,9 @@ if sub:
     from nlos_stamped import mesh_io
     vv, ff = mesh_io.subdivide(vv, ff, sub)
 v = torch.from_numpy(vv).to(dev); f = torch.from_numpy(ff).to(dev)
-ns = 4 * ff.shape[0]
-g = torch.linspace(-0.25, 0.25, 32, device=dev); o = torch.stack([g.repeat(32), g.repeat_interleave(32), torch.zeros(1024, device=dev)], 1).contiguous(); n = torch.tensor([[0, 0, 1.0]] * 1024, device=dev)
+ns = int(os.environ.get("NLOS_STAMP_NS", str(4 * ff.shape[0])))
+G = int(os.environ.get("NLOS_STAMP_GRID", "32"))
+g = torch.linspace(-0.25, 0.25, G, device=dev); o = torch.stack([g.repeat(G), g.repeat_interleave(G), torch.zeros(G * G, device=dev)], 1).contiguous(); n = torch.tensor([[0, 0, 1.0]] * (G * G), device=dev)
 for _ in range(3):
     r.render_transient(o, n, v, f, ns, 0.625, 1.625, 2.0 ** -9)
 torch.cuda.synchronize()

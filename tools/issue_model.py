@@ -13,11 +13,15 @@
 Output: JSON with valu_busy {lo, central, hi} = issue cycles / (1024 SIMDs x kernel time x clock), the scalar unit's
 share, and the basis."""
 import json
+import os
 import re
 import sys
 
 FULL, HALF, QUARTER, SALU = 2.3, 4.1, 8.1, 4.15
-N_SIMD, CLOCK = 1024, 2.4e9
+N_SIMD = 1024
+# engine clock: measured on the forward kernel itself (tools/build_stamps.sh -> clock.json -> NLOS_CLOCK_GHZ, set by
+# tools/round_summary.py) when available, else the 2.4 GHz peak (then `busy` is a lower bound)
+CLOCK = float(os.environ.get("NLOS_CLOCK_GHZ", "2.4")) * 1e9
 
 FULL_OPS = re.compile(r"^v_(add|sub|subrev|mul|fma|fmac|mac)_f32|^v_(add|sub|subrev)_u32|^v_(and|or|xor|not)_b32|^v_mov_b32|^v_bitop3|^v_add_nc")
 SKIP = re.compile(r"^v_(sqrt|rcp|rsq|exp|log|sin|cos)_f32|_f64|^v_cvt|^v_pk_|^v_mad_u64|^v_lshl_add_u64|^v_lshlrev_b64|^v_lshrrev_b64|^v_ashrrev_i64|^v_mfma")
@@ -75,7 +79,8 @@ def main():
                     "int32 + unclassified (2.3 ... 4.1)": mixed},
         "mixed_full_rate_fraction": frac_full, "mixed_fraction_basis": "static ISA histogram" if share is not None else "50/50",
         "basis": "issue costs: profiles/r03_issue_rates.json (tools/issue_rate.hip, >= 2 waves per SIMD); counters: SQ_INSTS_VALU* "
-                 "(tools/pmc_classes.sh, separate --pmc passes); 1024 SIMDs, 2.4 GHz peak engine clock (a lower bound on busy); the "
+                 "(tools/pmc_classes.sh, separate --pmc passes); 1024 SIMDs, engine clock %.3f GHz (%s); the " % (CLOCK / 1e9, "measured on the forward kernel: s_memtime / s_memrealtime, tools/build_stamps.sh" if "NLOS_CLOCK_GHZ" in os.environ else "peak: a lower bound on busy") +
+                 "
                  "scalar unit serves one SIMD every 4.15 cycles and overlaps with vector issue of other waves",
     }
     print(json.dumps(out, indent=1))

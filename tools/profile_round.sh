@@ -1,5 +1,7 @@
 #!/bin/bash
 # Round profile: kernel-trace stats + HBM traffic counters (separate --pmc passes), summaries -> gpurun_out/profile_<tag>/
+# NLOS_GIT_HEAD=<hash> (the GPU box has no .git) is recorded in pmc_summary.json's stamp beside the hash of the kernel
+# sources, which is what bench.py matches.  Usage: gpurun -- "NLOS_GIT_HEAD=$(git rev-parse --short=12 HEAD) bash tools/profile_round.sh r04"
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profile_$TAG
@@ -12,6 +14,9 @@ timeout 120 rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_
 # VALU instruction classes for the weighted issue model (tools/issue_model.py; issue costs: profiles/r03_issue_rates.json)
 timeout 120 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 --output-format csv -d $OUT/cls1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --sustain-seconds 0 --prewarm-seconds 0 --share-steps 0 > $OUT/cls1.log 2>&1
 timeout 120 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE --output-format csv -d $OUT/cls2 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --sustain-seconds 0 --prewarm-seconds 0 --share-steps 0 > $OUT/cls2.log 2>&1
+# the shader clock the forward kernel runs at, on the metric workload (stamped copy of the library in /tmp): -> clock.json
+NLOS_STAMP_GRID=64 NLOS_STAMP_NS=20000 NLOS_CLOCK_JSON=$GRAFT_REPO_ROOT/$OUT/clock.json timeout 600 bash tools/build_stamps.sh > $OUT/stamps.log 2>&1
+cd "$GRAFT_REPO_ROOT"
 python3 tools/pmc_summary.py $OUT > $OUT/pmc_summary_all.json
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 python3 tools/trace_summary.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) > $OUT/kernel_trace_summary.json

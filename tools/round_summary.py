@@ -18,6 +18,8 @@ import sys
 
 root, L, F = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 here = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(here, ".."))
+from nlos_surface_optimization_amd import _lib  # noqa: E402  (source_stamp only: no GPU call)
 pmc = json.load(open(os.path.join(root, "pmc_summary_all.json")))
 trace = json.load(open(os.path.join(root, "kernel_trace_summary.json")))
 
@@ -32,9 +34,19 @@ fw_name, fw = pick(pmc, "k_forward_grid")
 gr_name, gr = pick(pmc, "k_gradient")
 _, fw_t = pick(trace, "k_forward_grid")
 _, gr_t = pick(trace, "k_gradient")
-out = {"kernel": "k_forward", "L": L, "F": F,
+# which build these counters belong to: bench.py matches `source_sha256_16` and reports the set as stale otherwise.
+# `git` is the HEAD of the build container at profile time when tools/profile_round.sh was handed one (NLOS_GIT_HEAD;
+# the GPU box has no .git), `clock_ghz` the shader clock of the issue model (tools/clock_probe: s_memtime ticks of the
+# forward kernel / its HIP-event time) if the profile directory holds one.
+stamp = _lib.source_stamp()
+stamp["git"] = os.environ.get("NLOS_GIT_HEAD") or None
+clock = None
+if os.path.exists(os.path.join(root, "clock.json")):
+    clock = json.load(open(os.path.join(root, "clock.json")))
+out = {"kernel": "k_forward", "L": L, "F": F, "stamp": stamp,
        "hbm_bytes_per_launch": 1024.0 * (2 * fw["FETCH_SIZE"] + fw["WRITE_SIZE"]),
        "fetch_size_kb": fw["FETCH_SIZE"], "write_size_kb": fw["WRITE_SIZE"],
+       "clock": clock,
        "note": "steady-state means of the largest launches, rocprofv3 --pmc in separate passes (tools/profile_round.sh); "
                "FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md"}
 
@@ -44,7 +56,10 @@ def model(name, ms):
     isa = os.environ.get("NLOS_ISA", os.path.join(root, "forward_grid.s"))
     cmd = [sys.executable, os.path.join(here, "issue_model.py"), os.path.join(here, "..", "profiles", "r03_issue_rates.json"),
            os.path.join(root, "pmc_summary_all.json"), name, "%.6f" % ms] + ([isa] if os.path.exists(isa) else [])
-    return json.loads(subprocess.check_output(cmd))
+    env = dict(os.environ)
+    if clock and clock.get("clock_ghz"):
+        env["NLOS_CLOCK_GHZ"] = "%.5f" % clock["clock_ghz"]
+    return json.loads(subprocess.check_output(cmd, env=env))
 
 
 dur_ms = fw_t["steady_mean_ms"] if fw_t else None
