@@ -13,6 +13,8 @@ Reads /root/reference (read-only, absent on the GPU box) and writes DATA only:
                       closest-hit / distance / binning primitives against reference code
   pyref_angular_nc.npz  the same prototype with lighting != sensor (row N, non-confocal pairs), incl. a
                       blocker that hides paths from one end point only
+  pyref_radiometry.npz  the same prototype with 2 000 000 hemisphere directions per source on wall-parallel patches, in 40
+                      batches: the statistical pin of the v2 radiometry (A ff^2 / spt, 1 / h^4, binning origin)
   jitter_info.npz     jitter/jitter_info.mat (the reference's measured SPAD jitter kernel) as npz
   adam_modified.npz   parameter trajectories of the reference's own optimiser class
                       (exp_bunny/adam_modified.py, imported and run on CPU) on fixed gradients
@@ -243,6 +245,101 @@ def make_pyref_grad():
     np.savez_compressed(os.path.join(HERE, "pyref_angular_grad.npz"), **out)
 
 
+def radiometry_scenes():
+    """Scenes of the statistical radiometry pin: wall-PARALLEL patches, so that the wall cosine of a path of length 2h
+    is z_patch / h -- a function of the time bin -- and can be divided out of the v2 rows bin by bin.
+      plane  the cfg-1 plane (z = 0.38, +-0.25 m), two wall-facing triangles
+      steps  a far square (z = 0.60, +-0.30 m) partly hidden behind a near one (z = 0.40): the near patch's paths end
+             at 2h <= 0.98 m, the far patch's start at 1.2 m, so every bin belongs to one depth
+    Sources: the four confocal points of the prototype fixtures."""
+    v, f, _, _ = cfg1()
+    sv = np.array([[-.30, -.30, .60], [.30, -.30, .60], [.30, .30, .60], [-.30, .30, .60],
+                   [-.10, -.12, .40], [.15, -.12, .40], [.15, .08, .40], [-.10, .08, .40]], np.float64)
+    sf = np.array([[0, 2, 1], [0, 3, 2], [4, 6, 5], [4, 7, 6]], np.int64)
+    src = np.array([[0.1, 0, 0], [-0.1, 0, 0], [0, 0.1, 0], [0, -0.1, 0]], np.float64)
+    return {"plane": dict(v=v.astype(np.float64), f=f.astype(np.int64), nbin=80, zsplit=1e9, z=(0.38, 0.38), src=src, moved=True),
+            "steps": dict(v=sv, f=sf, nbin=104, zsplit=1.1, z=(0.40, 0.60), src=src, moved=False)}
+
+
+def make_pyref_radiometry():
+    """Statistical pin of the v2 radiometry against data the REFERENCE produced (round 4).  The reference's numpy
+    prototype (transient_rendering_python/rendering.py:angular_sampling, imported) is an angular estimator: with
+    directions uniform on the hemisphere it integrates cos(theta_2) / d_2^2 over solid angle, i.e. the surface
+    integral of cos(theta_1) cos(theta_2) / (d_1^2 d_2^2) over the visible surface (rendering.py:82-93).  The v2
+    renderer the oracle restates is an AREA estimator of the same surface term times the two wall cosines
+    (smoothed_transient/transient_and_gradient.cpp:224-232: A ff^2 / spt, ff = cos_surface cos_wall / h^2).  On
+    wall-parallel patches cos_wall = z_patch / h is known per bin, so the two must agree bin by bin within the
+    Monte-Carlo error: that pins A / spt, the two-way 1 / h^4, the clamped cosines and the binning origin
+    (ceil(d / res) - 1 there, floor((2h - lb) / res) here) against reference output.
+    2 000 000 directions per source, in 40 batches of 50 000 (the batch spread is the error estimate the test uses);
+    directions: numpy RandomState(4242), uniform on the upper hemisphere (z = U(0, 1), phi = U(0, 2 pi)), drawn batch
+    by batch in the order scene -> batch.  Only the histograms are stored."""
+    sys.path.insert(0, os.path.join(REF, "transient_rendering_python"))
+    import rendering as pyref  # noqa: E402  (the reference module)
+
+    rs = np.random.RandomState(4242)
+    nb, per = 40, 50000
+    res = 2.0 ** -6
+    delta = 0.005
+    out = {"res": np.float64(res), "batches": np.int64(nb), "per_batch": np.int64(per), "delta": np.float64(delta)}
+
+    def mesh_of(mv, mf):
+        mesh = types.SimpleNamespace()
+        mesh.v, mesh.f = mv, mf
+        p1, p2, p3 = mv[mf[:, 0]], mv[mf[:, 1]], mv[mf[:, 2]]
+        fn = np.cross(p2 - p1, p3 - p1)
+        mesh.fn = fn / np.linalg.norm(fn, axis=1, keepdims=True)
+        return mesh
+
+    for name, sc in radiometry_scenes().items():
+        mv, mf = sc["v"], sc["f"]
+        opt = types.SimpleNamespace(sample_num=per, max_distance_bin=sc["nbin"], distance_resolution=res, epsilon=1e-9, normal="fn")
+        # Finite-difference pin of the GRADIENT: every patch (4 vertices) is moved as a whole, keeping it wall-parallel --
+        # translations along x, y, z and an in-plane scaling about its centre -- by +-delta, with the SAME directions
+        # (common random numbers); the test differentiates functionals of the rows along these motions.  Only on the
+        # scene WITHOUT occlusion: the reference's analytic gradient holds visibility fixed (no silhouette term,
+        # smoothed_transient/transient_and_gradient.cpp:944-1001), so where a moving patch drags its shadow over another
+        # the finite difference of the true forward is a different quantity (measured on `steps`: 40 % apart).
+        npatch = mv.shape[0] // 4 if sc["moved"] else 0
+        motions = []
+        for k in range(npatch):
+            idx = np.arange(4 * k, 4 * k + 4)
+            c = mv[idx].mean(axis=0)
+            for m in range(4):
+                step = np.zeros_like(mv)
+                if m < 3:
+                    step[idx, m] = 1.0
+                else:
+                    step[idx, :2] = (mv[idx] - c)[:, :2]
+                motions.append(step)
+        motions = np.stack(motions) if motions else np.zeros((0,) + mv.shape)   # [npatch * 4, V, 3]: d vertex / d theta
+        rows = np.zeros((nb, sc["src"].shape[0], sc["nbin"]))
+        moved = np.zeros((motions.shape[0], 2, nb, sc["src"].shape[0], sc["nbin"]), np.float32)
+        for b in range(nb):
+            z = rs.uniform(0.0, 1.0, per)
+            ph = rs.uniform(0.0, 2 * np.pi, per)
+            r = np.sqrt(1.0 - z * z)
+            d = np.stack([r * np.cos(ph), r * np.sin(ph), z], 1)
+            for i, o in enumerate(sc["src"]):
+                up = np.array([0, 0, 1.0])
+                rows[b, i] = pyref.angular_sampling(mesh_of(mv, mf), d, o, o, up, up, opt)
+                for q in range(motions.shape[0]):
+                    for sgn in (0, 1):
+                        mq = mesh_of(mv + (delta if sgn == 0 else -delta) * motions[q], mf)
+                        moved[q, sgn, b, i] = pyref.angular_sampling(mq, d, o, o, up, up, opt)
+        out[name + "_v"], out[name + "_f"], out[name + "_src"] = mv, mf, sc["src"]
+        out[name + "_nbin"] = np.int64(sc["nbin"])
+        out[name + "_z"] = np.array(sc["z"], np.float64)
+        out[name + "_zsplit"] = np.float64(sc["zsplit"])
+        out[name + "_rows"] = rows
+        if sc["moved"]:
+            out[name + "_motions"] = motions
+            out[name + "_moved"] = moved                                  # [motion, +/-, batch, source, bin]
+        m = rows.sum(axis=2)
+        print("pyref radiometry", name, "mass", m.mean(axis=0), "+-", m.std(axis=0, ddof=1) / np.sqrt(nb))
+    np.savez_compressed(os.path.join(HERE, "pyref_radiometry.npz"), **out)
+
+
 def make_jitter_info():
     """The reference's measured SPAD jitter kernel (a data file its own jitter/test.py loads)."""
     import scipy.io
@@ -347,6 +444,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
+    if "--radiometry-only" in sys.argv:
+        make_pyref_radiometry()
+        sys.exit(0)
     if "--measurement-only" in sys.argv:
         make_mannequin_measurement()
         sys.exit(0)
@@ -361,6 +461,7 @@ if __name__ == "__main__":
     make_pyref()
     make_pyref_nc()
     make_pyref_grad()
+    make_pyref_radiometry()
     make_jitter_info()
     make_adam_modified()
     make_oracle_cfg1()
