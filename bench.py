@@ -89,7 +89,7 @@ def counters_of_this_build(pmc, kernel, comparable, L, F):
 # CPU side of rank 0: the oracle as parity checker and as the reported baseline (never the product)
 # ------------------------------------------------------------------------------------------------
 def _oracle_block(v, f, origin, normal, lb, ub, res, num_sample, data_rows, n, threads, source_offset=0,
-                  forward_only=False, sensor=None, sensor_normal=None):
+                  forward_only=False, sensor=None, sensor_normal=None, source_stride=1):
     """Rows and vertex gradient of the first n sources of a block by the CPU oracle (total_sources = n; RNG keys
     of the block's global source indices); returns (transient, gradient or None, seconds).  The same call for every
     workload the bench can time: confocal forward + gradient, forward only, non-confocal pairs, any mesh."""
@@ -98,7 +98,7 @@ def _oracle_block(v, f, origin, normal, lb, ub, res, num_sample, data_rows, n, t
     o, nn = np.ascontiguousarray(origin[:n]), np.ascontiguousarray(normal[:n])
     d = np.ascontiguousarray(data_rows[:n])
     w = np.ones_like(d)
-    kw = dict(accel=1, threads=threads, seed=0, source_offset=int(source_offset))
+    kw = dict(accel=1, threads=threads, seed=0, source_offset=int(source_offset), source_stride=int(source_stride))
     t0 = time.perf_counter()
     if sensor is not None:
         tr, g, _ = oracle.render_nonconfocal(o, nn, np.ascontiguousarray(sensor[:n]), np.ascontiguousarray(sensor_normal[:n]),
@@ -188,7 +188,8 @@ def workload_config(args, g, T, F, V, spt, L_total, world):
                         g, g, "" if world == 1 else (" split over %d ranks" % world if args.scaling == "strong" else " per rank"),
                         T, args.mesh, F, V, args.num_sample, spt),
         "sources_total": L_total, "faces": F, "bins": T, "spt": spt,
-        "parallelism": "source-block sharding x%d + one all-reduce of the 3V gradient" % world,
+        "parallelism": "source sharding x%d (%s) + one all-reduce of the 3V gradient" % (
+            world, "one grid per rank" if args.scaling == "weak" else args.partition + " partition"),
     }
 
 
@@ -222,6 +223,10 @@ def parse_args(argv=None):
                     help="with --of N: side measurement on ONE GPU of what rank K of an N-rank strong split does per step "
                          "(its block of the grid, global source offsets and 1/L scaling, no collective)")
     ap.add_argument("--of", type=int, default=1, help="see --as-rank")
+    ap.add_argument("--partition", choices=["contiguous", "strided"], default="strided",
+                    help="strong scaling: which sources a rank owns -- a contiguous block of the grid (the reference's own "
+                         "batching, exp_bunny/test.py:66-67) or every N-th source (l = rank mod N: an even sample of the wall, "
+                         "so the ranks finish together; default).  Results do not depend on it (RNG keys are global).")
     ap.add_argument("--share-steps", type=int, default=10,
                     help="N = 1, metric workload: after the timed steps, time every rank's block of the 2-, 4- and 8-way strong "
                          "split for this many steps each and report them as `strong_share` (0 = skip)")
@@ -339,23 +344,26 @@ def run_rank(args, backend):
     else:
         origin_np, normal_np = grid_sources(g, g, 0.25)            # one 64x64 grid, split over the ranks
     L_total = origin_np.shape[0]
-    lo, hi = ndist.shard_bounds(L_total, rank, world)
+    partition = args.partition if args.scaling == "strong" else "contiguous"    # (weak: one whole grid per rank)
+    own, lo, stride = ndist.shard_slice(L_total, rank, world, partition)
     if args.of > 1:
         if world != 1 or not (0 <= args.as_rank < args.of):
             raise SystemExit("bench.py: --as-rank K --of N is a one-GPU side measurement (0 <= K < N, --gpus 1)")
-        lo, hi = ndist.shard_bounds(L_total, args.as_rank, args.of)
-    L = hi - lo
+        own, lo, stride = ndist.shard_slice(L_total, args.as_rank, args.of, partition)
+    origin_np, normal_np = np.ascontiguousarray(origin_np[own]), np.ascontiguousarray(normal_np[own])   # this rank's sources
+    L = origin_np.shape[0]
+    keys = {"source_offset": lo, "source_stride": stride}       # global index of local source l = lo + l * stride
 
     r = backend.make_renderer()
-    origin = torch.from_numpy(origin_np[lo:hi]).to(dev)
-    normal = torch.from_numpy(normal_np[lo:hi]).to(dev)
+    origin = torch.from_numpy(origin_np).to(dev)
+    normal = torch.from_numpy(normal_np).to(dev)
     faces = torch.from_numpy(f_np).to(dev)
     verts = torch.from_numpy(v_np).to(dev)
     # synthetic measurement: transient of a slightly displaced copy of the mesh, weight == 1
     rs = np.random.RandomState(0)
     v_gt = torch.from_numpy((v_np + 0.002 * rs.standard_normal(v_np.shape)).astype(np.float32)).to(dev)
     data, _ = r.render_transient(origin, normal, v_gt, faces, args.num_sample, lb, ub, res,
-                                 source_offset=lo, total_sources=L_total, seed=1)
+                                 total_sources=L_total, seed=1, **keys)
     weight = torch.ones_like(data)
     grad = torch.zeros((V, 3), dtype=torch.float64, device=dev)
     nc = {}
@@ -372,20 +380,21 @@ def run_rank(args, backend):
     wk = {"forward_only": bool(args.forward_only)}
     if args.non_confocal:
         wk.update(sensor=nc["sensor"].cpu().numpy(), sensor_normal=nc["sensor_normal"].cpu().numpy())
-    n_ref, t_ref, g_ref, cpu_base = cpu_reference(v_np, f_np, origin_np[lo:hi], normal_np[lo:hi], lb, ub, res,
-                                                  args.num_sample, data_np, budget, source_offset=lo, share=world, **wk)
+    n_ref, t_ref, g_ref, cpu_base = cpu_reference(v_np, f_np, origin_np, normal_np, lb, ub, res,
+                                                  args.num_sample, data_np, budget, source_offset=lo, share=world,
+                                                  source_stride=stride, **wk)
 
     def render_block(n):
         ncb = {k: t[:n].contiguous() for k, t in nc.items()}
         if args.forward_only:
             tb, _ = r.render_transient(origin[:n].contiguous(), normal[:n].contiguous(), verts, faces, args.num_sample,
-                                       lb, ub, res, source_offset=lo, total_sources=n, **ncb)
+                                       lb, ub, res, total_sources=n, **keys, **ncb)
             return tb.cpu().numpy(), None
         gb = torch.zeros((V, 3), dtype=torch.float64, device=dev)
         tb, gb, _ = r.render_gradient(origin[:n].contiguous(), normal[:n].contiguous(), verts, faces,
                                       args.num_sample, lb, ub, res, data=data[:n].contiguous(),
                                       weight=weight[:n].contiguous(), refine_scale=10, sigma_bin=1,
-                                      testing_flag=1, loss_flag=0, gradient=gb, source_offset=lo, total_sources=n, **ncb)
+                                      testing_flag=1, loss_flag=0, gradient=gb, total_sources=n, **keys, **ncb)
         return tb.cpu().numpy(), gb.cpu().numpy()
 
     parity = parity_gate(render_block, n_ref, t_ref, g_ref)
@@ -410,11 +419,11 @@ def run_rank(args, backend):
     def step():
         if args.forward_only:
             r.render_transient(origin, normal, verts, faces, args.num_sample, lb, ub, res,
-                               source_offset=lo, total_sources=L_total, **nc)
+                               total_sources=L_total, **keys, **nc)
         else:
             r.render_gradient(origin, normal, verts, faces, args.num_sample, lb, ub, res, data=data,
                               weight=weight, refine_scale=10, sigma_bin=1, testing_flag=1, loss_flag=0,
-                              gradient=grad, zero_gradient=True, source_offset=lo, total_sources=L_total, **nc)
+                              gradient=grad, zero_gradient=True, total_sources=L_total, **keys, **nc)
             if world > 1:
                 dist.all_reduce(grad, op=dist.ReduceOp.SUM)
 
@@ -484,27 +493,29 @@ def run_rank(args, backend):
     share = None
     if world == 1 and plain and args.share_steps > 0 and not diagnostic:
         share = {}
-        for n_split in (2, 4, 8):
-            per = []
-            for k in range(n_split):
-                klo, khi = ndist.shard_bounds(L_total, k, n_split)
-                o_k, n_k = origin[klo:khi].contiguous(), normal[klo:khi].contiguous()
-                d_k, w_k = data[klo:khi].contiguous(), weight[klo:khi].contiguous()
+        for part in ndist.PARTITIONS:
+            share[part] = {}
+            for n_split in (2, 4, 8):
+                per = []
+                for k in range(n_split):
+                    ksl, klo, kstride = ndist.shard_slice(L_total, k, n_split, part)
+                    o_k, n_k = origin[ksl].contiguous(), normal[ksl].contiguous()
+                    d_k, w_k = data[ksl].contiguous(), weight[ksl].contiguous()
 
-                def step_k():
-                    r.render_gradient(o_k, n_k, verts, faces, args.num_sample, lb, ub, res, data=d_k, weight=w_k,
-                                      refine_scale=10, sigma_bin=1, testing_flag=1, loss_flag=0, gradient=grad,
-                                      zero_gradient=True, source_offset=klo, total_sources=L_total)
-                for _ in range(3):
-                    step_k()
-                backend.sync()
-                t0 = time.perf_counter()
-                for _ in range(args.share_steps):
-                    step_k()
-                backend.sync()
-                per.append(1e3 * (time.perf_counter() - t0) / args.share_steps)
-            share[str(n_split)] = {"per_rank_ms": per, "max_ms": max(per),
-                                   "efficiency_without_collective": (1e3 * elapsed / args.steps) / (n_split * max(per))}
+                    def step_k():
+                        r.render_gradient(o_k, n_k, verts, faces, args.num_sample, lb, ub, res, data=d_k, weight=w_k,
+                                          refine_scale=10, sigma_bin=1, testing_flag=1, loss_flag=0, gradient=grad,
+                                          zero_gradient=True, source_offset=klo, source_stride=kstride, total_sources=L_total)
+                    for _ in range(3):
+                        step_k()
+                    backend.sync()
+                    t0 = time.perf_counter()
+                    for _ in range(args.share_steps):
+                        step_k()
+                    backend.sync()
+                    per.append(1e3 * (time.perf_counter() - t0) / args.share_steps)
+                share[part][str(n_split)] = {"per_rank_ms": per, "max_ms": max(per), "spread": (max(per) - min(per)) / min(per),
+                                             "efficiency_without_collective": (1e3 * elapsed / args.steps) / (n_split * max(per))}
 
     if diagnostic:
         if rank == 0:
@@ -541,11 +552,12 @@ def run_rank(args, backend):
         if parity is not None:
             out["parity"] = parity
         if args.of > 1:
-            out["as_rank"] = {"rank": args.as_rank, "of": args.of, "sources": [lo, hi],
+            out["as_rank"] = {"rank": args.as_rank, "of": args.of, "partition": partition, "first_source": lo, "source_stride": stride, "sources": L,
                               "note": "one GPU timing what rank %d of a %d-rank strong split does per step (no collective); "
                                       "`value` counts this block's samples only" % (args.as_rank, args.of)}
         if share is not None:
-            share["note"] = ("measured on ONE GPU: every rank's block of the N-way strong split of this grid, %d steps each, "
+            share["note"] = ("measured on ONE GPU: every rank's sources of the N-way strong split of this grid, for both partitions "
+                             "(contiguous blocks / every N-th source), %d steps each, "
                              "scene build replicated, NO all-reduce (a 3V-double RCCL all-reduce per step comes on top); "
                              "efficiency_without_collective = ms_per_step / (N x slowest block)" % args.share_steps)
             out["strong_share"] = share

@@ -308,6 +308,12 @@ typedef struct nlos_render_args {
      * the rounding of the hit's barycentrics, i.e. a sample within ~1e-7 of a bin edge changes bins).  Runs on the BVH
      * back-end; nlos_v1_render_transient sets it together with clamp = 0. */
     int32_t v1_sampled_point;
+    /* Global index of origin[l] = source_offset + l * source_stride (0 or 1: a contiguous block, the reference's own
+     * batching, exp_bunny/test.py:66-67).  N > 1 with source_offset = rank: the STRIDED partition of an N-way
+     * split (l = rank mod N) -- every rank then holds an even sample of the wall instead of one corner of it, which
+     * balances the ranks (sources under the object are the slowest).  RNG keys are global, so the union of the
+     * shards' rows and the sum of their gradients do not depend on the partition. */
+    int32_t source_stride;
 } nlos_render_args;
 
 int  nlos_sizeof_render_args(void);                 /* for FFI layout checks */

@@ -74,6 +74,7 @@ class RenderArgs(ctypes.Structure):
         ("visibility_generation", ctypes.c_int64),
         ("zero_gradient", ctypes.c_int32),
         ("v1_sampled_point", ctypes.c_int32),
+        ("source_stride", ctypes.c_int32),
     ]
 
 

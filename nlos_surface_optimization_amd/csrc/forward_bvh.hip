@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_forward(ForwardArgs a, int rows_in_lds)
 
     const V3 o = ld3(a.src.origin + 3 * (size_t)l);
     const V3 on = ld3(a.src.normal + 3 * (size_t)l);
-    const uint64_t lg = (uint64_t)(a.src.source_offset + l);
+    const uint64_t lg = (uint64_t)(a.src.source_offset + (long long)l * a.src.source_stride);
     const int spt = a.sp.spt;
     const float lb = a.sp.lb, ub = a.sp.ub, res = a.sp.res;
     double* grow = a.rows ? a.rows + (size_t)l * nbins : nullptr;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void k_forward_nc(ForwardArgs a, int rows_in_l
 
     const V3 oa = ld3(a.src.origin + 3 * (size_t)l), na = ld3(a.src.normal + 3 * (size_t)l);
     const V3 ob = ld3(a.src.sensor + 3 * (size_t)l), nb = ld3(a.src.sensor_normal + 3 * (size_t)l);
-    const uint64_t lg = (uint64_t)(a.src.source_offset + l);
+    const uint64_t lg = (uint64_t)(a.src.source_offset + (long long)l * a.src.source_stride);
     const int spt = a.sp.spt;
     const float lb = a.sp.lb, ub = a.sp.ub, res = a.sp.res;
     double* grow = a.rows + (size_t)l * nbins;

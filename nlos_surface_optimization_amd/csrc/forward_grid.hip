@@ -828,7 +828,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     //      test; hits are OR-ed into the wave's occlusion mask.
     // The kernel is VALU-issue bound and cell lists have a heavy tail, so the expensive stage must run on
     // dense lanes and must not wait for the longest list.
-    const uint64_t lg = (uint64_t)(a.src.source_offset + l);
+    const uint64_t lg = (uint64_t)(a.src.source_offset + (long long)l * a.src.source_stride);
     const int spt = a.sp.spt;
     const float lb = a.sp.lb, ub = a.sp.ub, res = a.sp.res;
     double* grow = a.rows ? a.rows + (size_t)l * nbins : nullptr;

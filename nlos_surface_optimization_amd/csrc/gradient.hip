@@ -136,7 +136,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
         const V3 on = ld3(a.src.normal + 3 * (size_t)l);
         const V3 ob = NC ? ld3(a.src.sensor + 3 * (size_t)l) : o;
         const V3 onb = NC ? ld3(a.src.sensor_normal + 3 * (size_t)l) : on;
-        const uint64_t lg = (uint64_t)(a.src.source_offset + l);
+        const uint64_t lg = (uint64_t)(a.src.source_offset + (long long)l * a.src.source_stride);
 
         for (;;) {
             const int b = wave_ticket(s_next);
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
             load_face_tri<FEAT | FEAT_VN>(a.sc, j, f, tr);    // vertices, ids, and the per-face constants the scene build evaluated
             const V3 o = ld3(a.src.origin + 3 * (size_t)l);
             const V3 on = ld3(a.src.normal + 3 * (size_t)l);
-            const uint64_t kbase = ((uint64_t)(a.src.source_offset + l) * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
+            const uint64_t kbase = ((uint64_t)(a.src.source_offset + (long long)l * a.src.source_stride) * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
             const uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
             double acc[9];
 #pragma unroll

@@ -108,7 +108,7 @@ struct nlos_ctx {
     // host-pointer path staging
     DevBuf io[16];
     // what the visibility cache currently describes
-    struct VisKey { int L = -1, F = -1, V = -1, spt = -1; long long off = -1; uint64_t seed = 0; float lb = 0, ub = 0;
+    struct VisKey { int L = -1, F = -1, V = -1, spt = -1; long long off = -1; int stride = 1; uint64_t seed = 0; float lb = 0, ub = 0;
                     int feat = -1; int64_t mesh_gen = -1; } vis_key;
     // timing
     // ring of event sets: no host sync inside a timed loop, read back after the final sync
@@ -531,6 +531,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     nlos::SourceView src;
     src.origin = a->origin; src.normal = a->normal; src.L = L;
     src.source_offset = a->source_offset; src.total_sources = a->total_sources;
+    src.source_stride = a->source_stride > 1 ? a->source_stride : 1;
     src.sensor = a->sensor; src.sensor_normal = a->sensor ? a->sensor_normal : nullptr;
 
     nlos::SampleParams sp;
@@ -631,7 +632,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         fa.vis2 = c->vis2.as<uint32_t>();
     }
     nlos_ctx::VisKey key;
-    key.L = L; key.F = nF; key.V = nV; key.spt = spt; key.off = a->source_offset; key.seed = a->seed;
+    key.L = L; key.F = nF; key.V = nV; key.spt = spt; key.off = a->source_offset; key.stride = a->source_stride > 1 ? a->source_stride : 1; key.seed = a->seed;
     key.lb = lb; key.ub = ub;
     key.feat = (vn ? 1 : 0) | (alb ? 2 : 0) | (sp.use_ggx ? 4 : 0) | (sp.clamp ? 8 : 0) | (a->sensor ? 16 : 0);
     key.mesh_gen = c->mesh_gen;
@@ -643,7 +644,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         if (a->visibility_generation == 0 || a->visibility_generation != c->vis_gen || k.mesh_gen != c->mesh_gen)
             return fail(NLOS_ERR_ARG, "nlos_render: reuse_visibility requested but the context no longer holds the visibility "
                                       "cache of that generation (another render or scene build ran on it since)");
-        if (!(k.L == key.L && k.F == key.F && k.V == key.V && k.spt == key.spt && k.off == key.off && k.seed == key.seed &&
+        if (!(k.L == key.L && k.F == key.F && k.V == key.V && k.spt == key.spt && k.off == key.off && k.stride == key.stride && k.seed == key.seed &&
               k.lb == key.lb && k.ub == key.ub && k.feat == key.feat))
             return fail(NLOS_ERR_ARG, "nlos_render: reuse_visibility requested but the cache does not match this render");
     }
@@ -694,7 +695,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         fc.src.L = L - l0 < chunk_L ? L - l0 : chunk_L;
         fc.src.origin += 3 * (size_t)l0; fc.src.normal += 3 * (size_t)l0;
         if (fc.src.sensor) { fc.src.sensor += 3 * (size_t)l0; fc.src.sensor_normal += 3 * (size_t)l0; }
-        fc.src.source_offset += l0;
+        fc.src.source_offset += (long long)l0 * fc.src.source_stride;
         if (fc.rows) fc.rows += (size_t)l0 * rb;
         if (fc.vis) fc.vis += (size_t)l0 * vis_words * nF;
         if (fc.vis2) fc.vis2 += (size_t)l0 * vis_words * nF;

@@ -72,6 +72,7 @@ struct SourceView {
     const float* normal;     // [L,3]
     int L;
     long long source_offset; // global index of origin[0]
+    int source_stride;       // global index of origin[l] = source_offset + l * source_stride (>= 1)
     int total_sources;       // for 1/L
     // row N (non-confocal pairs): sensor point / wall normal of pair l; null = confocal
     const float* sensor;     // [L,3] or null

@@ -119,7 +119,7 @@ class TransientRenderer:
 
     def _args(self, mode, origin, normal, vertices, faces, num_sample, lower_bound, upper_bound,
               resolution, refine_scale=1, sigma_bin=1, vertex_normal=None, albedo=None,
-              source_offset=0, total_sources=0, alpha=None, seed=None, force_bvh=False,
+              source_offset=0, total_sources=0, alpha=None, seed=None, force_bvh=False, source_stride=1,
               sensor=None, sensor_normal=None, jitter_weight=None, jitter_grad=None, jitter_offset=0):
         a = _lib.RenderArgs()
         self._lib.nlos_render_args_init(ctypes.byref(a))
@@ -132,6 +132,7 @@ class TransientRenderer:
         a.mode = mode
         a.origin, a.normal, a.L = _dptr(origin), _dptr(normal), origin.shape[0]
         a.source_offset, a.total_sources = int(source_offset), int(total_sources)
+        a.source_stride = int(source_stride)
         a.vertices, a.V = _dptr(vertices), vertices.shape[0]
         a.faces, a.F = _dptr(faces), faces.shape[0]
         a.vertex_normal, a.albedo = _dptr(vertex_normal), _dptr(albedo)

@@ -22,6 +22,24 @@ def shard_bounds(n_sources, rank, world_size):
     return lo, hi
 
 
+PARTITIONS = ("contiguous", "strided")
+
+
+def shard_slice(n_sources, rank, world_size, partition="contiguous"):
+    """The sources of `rank` as a slice of range(n_sources), and (source_offset, source_stride) for the renderer.
+    contiguous: the block [lo, hi) of shard_bounds -- the reference's own batching (exp_bunny/test.py:66-67);
+    strided: every world_size-th source from `rank` (l = rank mod N).  On a wall grid a contiguous block is one
+    strip of the wall, and the strip under the object is the slowest (7 % spread over the 8 blocks of the benchmark);
+    a strided shard is an even sample of the whole wall, so the ranks finish together.  RNG keys are made of the GLOBAL
+    source index, so rows and reduced gradient do not depend on the partition."""
+    if partition not in PARTITIONS:
+        raise ValueError("partition must be one of %s" % (PARTITIONS,))
+    if partition == "contiguous":
+        lo, hi = shard_bounds(n_sources, rank, world_size)
+        return slice(lo, hi), lo, 1
+    return slice(int(rank), int(n_sources), int(world_size)), int(rank), int(world_size)
+
+
 def all_reduce_gradient(gradient, group=None):
     """Sum the per-rank partial vertex gradients in place (no-op without a process group)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -30,14 +48,14 @@ def all_reduce_gradient(gradient, group=None):
 
 
 class ShardedRenderer:
-    """Renders this rank's source block and all-reduces the vertex gradient.
+    """Renders this rank's sources and all-reduces the vertex gradient.
 
     `renderer` is a device.TransientRenderer (or any object with the same
     render_transient / render_gradient methods: the CPU tests plug in a stand-in to cover
-    the sharding and collective logic under gloo).
+    the sharding and collective logic under gloo).  `partition`: see shard_slice().
     """
 
-    def __init__(self, renderer, n_sources, rank=None, world_size=None, group=None):
+    def __init__(self, renderer, n_sources, rank=None, world_size=None, group=None, partition="contiguous"):
         if rank is None:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
         if world_size is None:
@@ -45,24 +63,32 @@ class ShardedRenderer:
         self.renderer = renderer
         self.n_sources = int(n_sources)
         self.rank, self.world_size, self.group = rank, world_size, group
-        self.lo, self.hi = shard_bounds(n_sources, rank, world_size)
+        self.partition = partition
+        self.slice, self.offset, self.stride = shard_slice(n_sources, rank, world_size, partition)
+        self.lo, self.hi = shard_bounds(n_sources, rank, world_size)   # (contiguous partition; kept for callers that index by block)
+
+    def _keys(self):
+        kw = dict(source_offset=self.offset, total_sources=self.n_sources)
+        if self.stride != 1:
+            kw["source_stride"] = self.stride
+        return kw
 
     def local(self, per_source):
-        """Slice a [L_global, ...] tensor down to this rank's block (a view, no copy)."""
-        return per_source[self.lo:self.hi]
+        """This rank's rows of a [L_global, ...] tensor: a view for the contiguous partition, a contiguous COPY for the
+        strided one (the kernels read dense [L_local, ...] arrays; inputs are sliced once, outside the step loop)."""
+        part = per_source[self.slice]
+        return part if self.stride == 1 else part.contiguous()
 
     def render_transient(self, origin, normal, *args, **kw):
-        return self.renderer.render_transient(origin, normal, *args, source_offset=self.lo,
-                                              total_sources=self.n_sources, **kw)
+        return self.renderer.render_transient(origin, normal, *args, **self._keys(), **kw)
 
     def render_gradient(self, origin, normal, *args, **kw):
-        """origin/normal/data/weight are the LOCAL blocks. Returns (local transient rows,
+        """origin/normal/data/weight are the LOCAL rows (self.local(...)). Returns (local transient rows,
         globally reduced gradient, pathlengths).  A caller-supplied `gradient=` buffer is accumulated into as
         the renderer does (v2 semantics) -- AFTER the reduction, so that what it already holds (e.g. a
         regulariser gradient present on every rank) is not multiplied by the world size."""
         into = kw.pop("gradient", None)
-        transient, gradient, path = self.renderer.render_gradient(
-            origin, normal, *args, source_offset=self.lo, total_sources=self.n_sources, **kw)
+        transient, gradient, path = self.renderer.render_gradient(origin, normal, *args, **self._keys(), **kw)
         all_reduce_gradient(gradient, self.group)
         if into is not None:
             into += gradient
@@ -73,10 +99,13 @@ class ShardedRenderer:
         """Optional: assemble the full [L, T] transient on every rank (host asks for it rarely)."""
         if self.world_size == 1:
             return local_rows
-        sizes = [shard_bounds(self.n_sources, r, self.world_size) for r in range(self.world_size)]
-        maxrows = max(hi - lo for lo, hi in sizes)
-        pad = torch.zeros((maxrows, local_rows.shape[1]), dtype=local_rows.dtype, device=local_rows.device)
+        slices = [shard_slice(self.n_sources, r, self.world_size, self.partition)[0] for r in range(self.world_size)]
+        counts = [len(range(*sl.indices(self.n_sources))) for sl in slices]
+        pad = torch.zeros((max(counts), local_rows.shape[1]), dtype=local_rows.dtype, device=local_rows.device)
         pad[: local_rows.shape[0]] = local_rows
         out = [torch.empty_like(pad) for _ in range(self.world_size)]
         dist.all_gather(out, pad, group=self.group)
-        return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(out, sizes)], dim=0)
+        full = torch.empty((self.n_sources, local_rows.shape[1]), dtype=local_rows.dtype, device=local_rows.device)
+        for o, sl, n in zip(out, slices, counts):
+            full[sl] = o[:n]
+        return full

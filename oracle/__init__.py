@@ -29,6 +29,7 @@ class Opts(ctypes.Structure):
         ("ggx_alpha", ctypes.c_float),
         ("normal_term", ctypes.c_int32),
         ("clamp", ctypes.c_int32),
+        ("source_stride", ctypes.c_int32),
         ("sampled_point", ctypes.c_int32),
     ]
 
@@ -83,7 +84,7 @@ def rule_free():
 
 
 def make_opts(seed=0, source_offset=0, total_sources=0, accel=0, threads=0,
-              ggx_alpha=None, normal_term=-1, clamp=1, sampled_point=0):
+              ggx_alpha=None, normal_term=-1, clamp=1, sampled_point=0, source_stride=1):
     o = Opts()
     o.seed = seed
     o.source_offset = source_offset
@@ -95,6 +96,7 @@ def make_opts(seed=0, source_offset=0, total_sources=0, accel=0, threads=0,
     o.normal_term = normal_term
     o.clamp = clamp
     o.sampled_point = sampled_point
+    o.source_stride = int(source_stride)
     return o
 
 

@@ -88,6 +88,12 @@ void nlos_oracle_sample(uint64_t seed, uint64_t k, float *S, float *T) {
     *T = u32_to_unit((uint32_t)(z >> 32));
 }
 
+/* global index of source l of this call (source sharding: a contiguous block from source_offset, or every
+ * source_stride-th source from it); the sample keys are made of it */
+static inline uint64_t global_source(const nlos_oracle_opts *op, int l) {
+    return (uint64_t)(op->source_offset + (int64_t)l * (op->source_stride > 1 ? op->source_stride : 1));
+}
+
 void nlos_oracle_default_opts(nlos_oracle_opts *o) {
     memset(o, 0, sizeof(*o));
     o->normal_term = -1;
@@ -573,7 +579,7 @@ static void forward_task(const scene_t *sc, const float *origin, const float *no
     task_t t;
     task_setup(&t, sc, origin, normal, l, f, vnormal, albedo);
     if (t.degenerate) return;
-    uint64_t kbase = (((uint64_t)(op->source_offset + l)) * (uint64_t)sc->nF + (uint64_t)f) * (uint64_t)spt;
+    uint64_t kbase = ((global_source(op, l)) * (uint64_t)sc->nF + (uint64_t)f) * (uint64_t)spt;
     for (int s = 0; s < spt; ++s) {
         float S, T;
         geo_t g;
@@ -786,7 +792,7 @@ static void gradient_task(const scene_t *sc, const float *origin, const float *n
     task_t t;
     task_setup(&t, sc, origin, normal, l, f, vnormal, albedo);
     if (t.degenerate) return;
-    uint64_t kbase = (((uint64_t)(op->source_offset + l)) * (uint64_t)sc->nF + (uint64_t)f) * (uint64_t)spt;
+    uint64_t kbase = ((global_source(op, l)) * (uint64_t)sc->nF + (uint64_t)f) * (uint64_t)spt;
     const v3 e0 = sub3(t.p2, t.p1), e1 = sub3(t.p0, t.p2), e2 = sub3(t.p1, t.p0);
     const int vi[3] = {t.i0, t.i1, t.i2};
     for (int s = 0; s < spt; ++s) {
@@ -901,7 +907,7 @@ static double scalar_task(const scene_t *sc, const float *origin, const float *n
     double acc = 0;
     task_setup(&t, sc, origin, normal, l, f, NULL, albedo);
     if (t.degenerate) return 0;
-    uint64_t kbase = (((uint64_t)(op->source_offset + l)) * (uint64_t)sc->nF + (uint64_t)f) * (uint64_t)spt;
+    uint64_t kbase = ((global_source(op, l)) * (uint64_t)sc->nF + (uint64_t)f) * (uint64_t)spt;
     for (int s = 0; s < spt; ++s) {
         float S, T;
         geo_t g;
@@ -1000,7 +1006,7 @@ int nlos_oracle_render_intensity(const float *origin, int L, const float *normal
             task_t t;
             task_setup(&t, &sc, origin, normal, l, f, vnormal, NULL);
             if (t.degenerate) continue;
-            uint64_t kbase = (((uint64_t)(opts->source_offset + l)) * (uint64_t)nF + (uint64_t)f) * (uint64_t)spt;
+            uint64_t kbase = ((global_source(opts, l)) * (uint64_t)nF + (uint64_t)f) * (uint64_t)spt;
             for (int s = 0; s < spt; ++s) {
                 float S, T;
                 geo_t g;
@@ -1044,7 +1050,7 @@ int nlos_oracle_render_vertex_gradient(int vertex_num, const float *origin, int 
             task_setup(&t, &sc, origin, normal, l, f, NULL, NULL);
             if (t.i0 != vertex_num && t.i1 != vertex_num && t.i2 != vertex_num) continue;
             if (t.degenerate) continue;
-            uint64_t kbase = (((uint64_t)(opts->source_offset + l)) * (uint64_t)nF + (uint64_t)f) * (uint64_t)spt;
+            uint64_t kbase = ((global_source(opts, l)) * (uint64_t)nF + (uint64_t)f) * (uint64_t)spt;
             for (int s = 0; s < spt; ++s) {
                 float S, T;
                 geo_t g;
@@ -1130,7 +1136,7 @@ int nlos_oracle_render_gradient_v1(const double *data, const float *origin, int 
             task_t t;
             task_setup(&t, &sc, origin, normal, l, f, NULL, NULL);
             if (t.degenerate) continue;
-            uint64_t kbase = (((uint64_t)(op.source_offset + l)) * (uint64_t)nF + (uint64_t)f) * (uint64_t)spt;
+            uint64_t kbase = ((global_source(&op, l)) * (uint64_t)nF + (uint64_t)f) * (uint64_t)spt;
             const v3 e[3] = {sub3(t.p2, t.p1), sub3(t.p0, t.p2), sub3(t.p1, t.p0)};
             const int vi[3] = {t.i0, t.i1, t.i2};
             for (int s = 0; s < spt; ++s) {
@@ -1270,7 +1276,7 @@ static void jitter_gradient_task(const scene_t *sc, const float *origin, const f
     task_t t;
     task_setup(&t, sc, origin, normal, l, f, vnormal, NULL);
     if (t.degenerate) return;
-    uint64_t kbase = (((uint64_t)(op->source_offset + l)) * (uint64_t)sc->nF + (uint64_t)f) * (uint64_t)spt;
+    uint64_t kbase = ((global_source(op, l)) * (uint64_t)sc->nF + (uint64_t)f) * (uint64_t)spt;
     const v3 e0 = sub3(t.p2, t.p1), e1 = sub3(t.p0, t.p2), e2 = sub3(t.p1, t.p0);
     const int vi[3] = {t.i0, t.i1, t.i2};
     for (int s = 0; s < spt; ++s) {
@@ -1415,7 +1421,7 @@ static void forward_task_nc(const scene_t *sc, const float *laser, const float *
     task_setup(&t, sc, laser, lnormal, l, f, vnormal, albedo);
     if (t.degenerate) return;
     const v3 b = ld3(sensor + 3 * (size_t)l), bn = ld3(snormal + 3 * (size_t)l);
-    uint64_t kbase = (((uint64_t)(op->source_offset + l)) * (uint64_t)sc->nF + (uint64_t)f) * (uint64_t)spt;
+    uint64_t kbase = ((global_source(op, l)) * (uint64_t)sc->nF + (uint64_t)f) * (uint64_t)spt;
     for (int s = 0; s < spt; ++s) {
         float S, T;
         geo_nc_t g;
@@ -1488,7 +1494,7 @@ static void gradient_task_nc(const scene_t *sc, const float *laser, const float 
     task_setup(&t, sc, laser, lnormal, l, f, vnormal, albedo);
     if (t.degenerate) return;
     const v3 b = ld3(sensor + 3 * (size_t)l), bn = ld3(snormal + 3 * (size_t)l);
-    uint64_t kbase = (((uint64_t)(op->source_offset + l)) * (uint64_t)sc->nF + (uint64_t)f) * (uint64_t)spt;
+    uint64_t kbase = ((global_source(op, l)) * (uint64_t)sc->nF + (uint64_t)f) * (uint64_t)spt;
     const v3 e0 = sub3(t.p2, t.p1), e1 = sub3(t.p0, t.p2), e2 = sub3(t.p1, t.p0);
     const int vi[3] = {t.i0, t.i1, t.i2};
     for (int s = 0; s < spt; ++s) {

@@ -23,13 +23,13 @@ class OracleStandIn:
 
     def render_gradient(self, origin, normal, vertices, faces, num_sample, lb, ub, res, data=None, weight=None,
                         refine_scale=10, sigma_bin=1, testing_flag=1, loss_flag=0, gradient=None, source_offset=0,
-                        total_sources=0, seed=None, zero_gradient=False, **kw):
+                        total_sources=0, seed=None, zero_gradient=False, source_stride=1, **kw):
         import oracle
         t, g, p = oracle.render_gradient(origin.numpy(), normal.numpy(), vertices.numpy(), faces.numpy(), num_sample,
                                          lb, ub, res, data.numpy(), weight.numpy(), refine=refine_scale,
                                          sigma_bin=sigma_bin, testing_flag=testing_flag, loss_flag=loss_flag, accel=1,
                                          threads=self.threads, source_offset=source_offset, total_sources=total_sources,
-                                         seed=self.seed if seed is None else seed)
+                                         source_stride=source_stride, seed=self.seed if seed is None else seed)
         g = torch.from_numpy(g)
         if gradient is not None:
             if zero_gradient:
@@ -39,11 +39,12 @@ class OracleStandIn:
         return torch.from_numpy(t), g, torch.from_numpy(p)
 
     def render_transient(self, origin, normal, vertices, faces, num_sample, lb, ub, res, source_offset=0,
-                         total_sources=0, seed=None, **kw):
+                         total_sources=0, seed=None, source_stride=1, **kw):
         import oracle
         t, p = oracle.render_transient(origin.numpy(), normal.numpy(), vertices.numpy(), faces.numpy(), num_sample,
                                        lb, ub, res, accel=1, threads=self.threads, source_offset=source_offset,
-                                       total_sources=total_sources, seed=self.seed if seed is None else seed)
+                                       total_sources=total_sources, source_stride=source_stride,
+                                       seed=self.seed if seed is None else seed)
         return torch.from_numpy(t), torch.from_numpy(p)
 
 

@@ -62,15 +62,22 @@ def test_one_ranks_share_and_the_share_table():
     p = _run([sys.executable, STANDIN, "--gpus", "1", "--no-cpu-baseline", "--as-rank", "3", "--of", "4"] + SMALL)
     assert p.returncode == 0, p.stderr[-2000:]
     out = _json_line(p.stdout)
-    assert out["as_rank"]["sources"] == [12, 16] and out["parity"]["rows"] == 4 and out["parity"]["pass"]
+    ar = out["as_rank"]      # default partition: strided -- sources 3, 7, 11, 15 of the 16
+    assert (ar["partition"], ar["first_source"], ar["source_stride"], ar["sources"]) == ("strided", 3, 4, 4)
+    assert out["parity"]["rows"] == 4 and out["parity"]["pass"]
     assert "ONE RANK'S SHARE" in out["config"]["workload"] and "strong_share" not in out
+    p = _run([sys.executable, STANDIN, "--gpus", "1", "--no-cpu-baseline", "--as-rank", "3", "--of", "4", "--partition", "contiguous"] + SMALL)
+    assert p.returncode == 0, p.stderr[-2000:]
+    ar = _json_line(p.stdout)["as_rank"]
+    assert (ar["partition"], ar["first_source"], ar["source_stride"], ar["sources"]) == ("contiguous", 12, 1, 4)
     small = [a for a in SMALL]
     small[small.index("--share-steps") + 1] = "1"
     p = _run([sys.executable, STANDIN, "--gpus", "1", "--no-cpu-baseline"] + small)
     assert p.returncode == 0, p.stderr[-2000:]
     out = _json_line(p.stdout)
-    sh = out["strong_share"]
-    assert [len(sh[k]["per_rank_ms"]) for k in ("2", "4", "8")] == [2, 4, 8] and sh["8"]["max_ms"] > 0
+    for part in ("contiguous", "strided"):
+        sh = out["strong_share"][part]
+        assert [len(sh[k]["per_rank_ms"]) for k in ("2", "4", "8")] == [2, 4, 8] and sh["8"]["max_ms"] > 0
 
 
 def test_side_workloads_are_gated_too():

@@ -68,5 +68,25 @@ def test_rccl_group_and_sharded_blocks(bunny):
             acc += g
         assert rel_l2(torch.cat(rows).cpu().numpy(), t_ref.cpu().numpy()) < 1e-12   # rows depend on their own source only
         assert rel_l2(acc.cpu().numpy(), g_ref.cpu().numpy()) < 1e-6    # summation order, through the fp32 residual of the tap loop
+
+        # the STRIDED partition (every N-th source, source_stride = N): the same rows, interleaved, and the same sum --
+        # and a strided shard agrees with the oracle rendering the same shard (keys of the global source indices)
+        import oracle
+        acc = torch.zeros_like(g_ref)
+        full = torch.zeros_like(t_ref)
+        for rank in range(3):
+            part = ShardedRenderer(r, L, rank=rank, world_size=3, partition="strided")
+            assert (part.offset, part.stride) == (rank, 3) and part.local(origin).is_contiguous()
+            t, g, _ = part.render_gradient(part.local(origin), part.local(normal), v, f, ns, LB, UB, RES,
+                                           data=part.local(data), weight=part.local(weight))
+            full[part.slice] = t
+            acc += g
+            if rank == 1:
+                t_o, g_o, _ = oracle.render_gradient(origin_np[1::3], normal_np[1::3], v_np, f_np, ns, LB, UB, RES,
+                                                     part.local(data).cpu().numpy(), part.local(weight).cpu().numpy(),
+                                                     accel=1, seed=5, source_offset=1, source_stride=3, total_sources=L)
+                assert rel_l2(t.cpu().numpy(), t_o) < 1e-12 and rel_l2(g.cpu().numpy(), g_o) < 1e-4
+        assert rel_l2(full.cpu().numpy(), t_ref.cpu().numpy()) < 1e-12
+        assert rel_l2(acc.cpu().numpy(), g_ref.cpu().numpy()) < 1e-6
     finally:
         dist.destroy_process_group()
