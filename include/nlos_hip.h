@@ -144,6 +144,19 @@ int nlos_nonconfocal_render_gradient(double *data, double *weight, float *laser,
         float resolution, double *transient, double *pathlengths, double *gradient,
         int refine_scale, int sigma_bin, int testing_flag, int loss_test);
 
+/* The product of a laser set and a sensor set (nlos_render_args.n_sensors): transient / data / weight are
+ * [numLasers, numSensors, numBins]; every (laser, sensor) combination is a pair of the functions above, rendered on
+ * samples shared by all wall points. */
+int nlos_nonconfocal_product_render_transient(float *laser, float *laserNormal, int numLasers, float *sensor,
+        float *sensorNormal, int numSensors, float *vertices, int numVertices, int *triangles, int numTriangles,
+        int numSamples, float lowerBound, float upperBound, float resolution,
+        double *transient, double *pathlengths);
+int nlos_nonconfocal_product_render_gradient(double *data, double *weight, float *laser, float *laserNormal,
+        int numLasers, float *sensor, float *sensorNormal, int numSensors, float *vertices, int numVertices,
+        int *triangles, int numTriangles, int numSamples, float lowerBound, float upperBound,
+        float resolution, double *transient, double *pathlengths, double *gradient,
+        int refine_scale, int sigma_bin, int testing_flag, int loss_test);
+
 /* the same with the GGX BRDF of the `ggx` module (`float alpha` after numTriangles, as ggx/...Renderer.h place it):
  * brdf = D(n.h) G1(n.w_laser) G1(n.w_sensor) / 4 with the half vector h -- ggx_confocal.cpp's eval() for
  * w_laser == w_sensor */
@@ -314,6 +327,21 @@ typedef struct nlos_render_args {
      * balances the ranks (sources under the object are the slowest).  RNG keys are global, so the union of the
      * shards' rows and the sum of their gradients do not depend on the partition. */
     int32_t source_stride;
+    /* 1: every source draws the SAME sample points -- the RNG key of sample s of face f is (source_offset * F + f) * spt + s
+     * for all of them (the product below is defined on such samples; also valid for plain confocal / pair renders). */
+    int32_t shared_samples;
+    /* Row N as a PRODUCT (north_star's L x S x T histogram): n_sensors > 0 makes `sensor` / `sensor_normal` arrays of
+     * n_sensors wall points of their own, and the measurements the L * n_sensors (laser, sensor) combinations:
+     * transient, data, weight (and residual rows) are [L, n_sensors, T], measurement (l, j) = pair (origin[l], sensor[j])
+     * of row N on shared samples (shared_samples is implied).  The reference has no native counterpart (prototype
+     * formulas: transient_rendering_python/mesh_optimization/rendering.py:739-797); the product is DEFINED as its
+     * pairs: results equal nlos_render of the L * n_sensors enumerated pairs with shared_samples = 1 up to fp64
+     * summation order.  With face normals, no albedo, Lambertian, 64 <= F <= 6200, spt <= 32 the work is O(L + S) grid
+     * passes (one visibility + geometry record per wall point) plus one combine kernel over the pairs, instead of two
+     * grid passes per pair; anything else is rendered as the enumerated pairs.  TRANSIENT and GRADIENT modes.
+     * gradient normalisation: 1 / (total_sources * n_sensors).  product_pairs = 1 (diagnostic): always enumerate. */
+    int32_t n_sensors;
+    int32_t product_pairs;
 } nlos_render_args;
 
 int  nlos_sizeof_render_args(void);                 /* for FFI layout checks */

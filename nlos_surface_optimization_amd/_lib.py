@@ -75,6 +75,9 @@ class RenderArgs(ctypes.Structure):
         ("zero_gradient", ctypes.c_int32),
         ("v1_sampled_point", ctypes.c_int32),
         ("source_stride", ctypes.c_int32),
+        ("shared_samples", ctypes.c_int32),
+        ("n_sensors", ctypes.c_int32),
+        ("product_pairs", ctypes.c_int32),
     ]
 
 
@@ -140,6 +143,8 @@ SYMBOLS = {
     "nlos_mesh_regulariser": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _I, _P]),
     "nlos_jitter_streamed_render_transient": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _P, _I, _I, _P, _P]),
     "nlos_jitter_streamed_render_gradient": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F, _P, _P, _I, _I, _P, _P, _P, _I]),
+    "nlos_nonconfocal_product_render_transient": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P]),
+    "nlos_nonconfocal_product_render_gradient": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _I, _I, _I, _I]),
     "nlos_nonconfocal_render_transient": (_I, [_P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _I, _I]),
     "nlos_nonconfocal_render_gradient": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _I, _I, _I, _I]),
     "nlos_ggx_nonconfocal_render_transient": (_I, [_P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _F, _I, _F, _F, _F, _P, _P, _I, _I]),

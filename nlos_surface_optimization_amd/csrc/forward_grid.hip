@@ -176,7 +176,9 @@ __device__ __forceinline__ void raster_cells(float gx0, float gy0, float inv_cw,
             for (int xx = cx0; xx <= cx1; ++xx) fn(xx, yy);
         return;
     }
-    // edge functions, oriented so that the inside is >= 0
+    {   // edge functions, oriented so that the inside is >= 0.  (Conservative arithmetic, so `#pragma clang fp contract(fast)`
+        // would be legitimate here and in make_entry(): 20 of the counting pass's 497 instructions, and no measurable
+        // time -- forward 1.346 vs 1.345 ms, profiles/r04_ab_contract_freeh.log; not kept.)
     const float area = (q.bx - q.ax) * (q.cy - q.ay) - (q.by - q.ay) * (q.cx - q.ax);
     const float sgn = area < 0.0f ? -1.0f : 1.0f;
     const bool thin = fabsf(area) < 1e-4f * cw * ch;         // edge-on: bbox cells only
@@ -201,6 +203,7 @@ __device__ __forceinline__ void raster_cells(float gx0, float gy0, float inv_cw,
             r0 += ax0; r1 += ax1; r2 += ax2;
         }
         E0 += by0; E1 += by1; E2 += by2;
+    }
     }
 }
 // first cell of the bounding box as raster_cells() derives it (same expressions, same bits)
@@ -372,7 +375,8 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     const V3 onb = NCM == 2 ? ld3(a.src.sensor_normal + 3 * (size_t)l) : on;
     uint32_t* const visout = NCM == 1 ? a.vis2 : a.vis;
     // item-mask layout of the visibility cache (launcher: single-workgroup grid, confocal; then a.vis == nullptr)
-    unsigned long long* const vitems = (!TILED && NCM == 0 && a.vis_items) ? a.vis_items + (size_t)l * (size_t)a.items_stride : nullptr;
+    // (the laser pass of non-confocal pairs records the pair's accepted samples the same way, round 4)
+    unsigned long long* const vitems = (!TILED && (NCM == 0 || NCM == 2) && a.vis_items) ? a.vis_items + (size_t)l * (size_t)a.items_stride : nullptr;
 #ifdef NLOS_FWD_STAMPS
     // diagnostic build only: per-phase cycles summed over workgroups -> a.dbg[0..5]
     long long t_prev = clock64();
@@ -939,6 +943,28 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     bin = (int)floorf((2.0f * gg.h - lb) / res);
                     dir = gg.dir;
                 }
+            } else if (NCM == 3) {
+                // record pass of the product (row N as L x S): this wall point's leg of every pair it takes part in --
+                // the expressions of sample_geo_nc() for one end point.  Path length of the leg and its clamped form factor
+                // travel through the trace in `bin` / `val` and are stored for the samples the wall point sees.
+                if (ok) {
+                    float S, T;
+                    sample_st(a.sp.seed, key, S, T);
+                    const float sq = sqrtf(T);
+                    const V3 p = bary(1 - sq, f.p0, (1 - S) * sq, f.p1, S * sq, f.p2);
+                    const V3 d = p - o;
+                    dir = d * (1.0f / sqrtf(dot(d, d)));
+                    float hu, hv;
+                    ok = tri_test(tr, o, dir, t_self, hu, hv);
+                    if (ok) {
+                        const V3 q = bary(1.0f - hu - hv, f.p0, hu, f.p1, hv, f.p2);
+                        const V3 e = q - o;
+                        const float dist = sqrtf(dot(e, e));
+                        val = emax0(-dot(f.fn, dir) * dot(on, dir) / dist / dist);
+                        bin = __float_as_int(dist);
+                        ok = val > 0.0f;
+                    }
+                }
             } else if (NCM == 1) {
                 // sensor leg only: is the stratified point the closest hit seen from the sensor?
                 if (ok) {
@@ -1124,7 +1150,13 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 TACC(tg);
             }
 
-            if (ok && NCM != 1) {
+            if (NCM == 3) {
+                if (ok) {
+                    const size_t at = (size_t)l * ((size_t)F * (size_t)spt) + (size_t)jg * (size_t)spt + (size_t)s;
+                    a.rec_d[at] = __int_as_float(bin);
+                    a.rec_ff[at] = val;
+                }
+            } else if (ok && NCM != 1) {
                 // (double)val / spt as the reference bins it, up to the rounding of 1 / spt (below the order-of-
                 // summation noise of the fp64 rows)
                 const double cc = (double)val * inv_spt;
@@ -1231,7 +1263,7 @@ bool forward_grid_launch(const ForwardArgs& a_in, int rows_in_lds, hipStream_t s
     // visibility cache: item masks where this launch can record them (confocal; the live list is its index), per-face
     // words otherwise -- never both
     ForwardArgs b = a_in;
-    const bool items = NCM == 0 && b.vis_items && b.vis;
+    const bool items = (NCM == 0 || NCM == 2) && b.vis_items && b.vis;
     if (items) b.vis = nullptr;
     else b.vis_items = nullptr;
     const ForwardArgs& a = b;
@@ -1363,9 +1395,19 @@ bool grid_dispatch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
 
 }  // namespace
 
+// record pass of the product: one launch of the single-workgroup grid per set of wall points (face normals, Lambertian);
+// false: this scene is outside that kernel's range (the caller then renders the enumerated pairs)
+bool launch_forward_record(const ForwardArgs& a, hipStream_t stream) {
+    if (!a.rec_d || !a.rec_ff || a.src.sensor || a.tile_list || feat_of(a.sc, a.sp) != 0) return false;
+    return forward_grid_launch<0, 3>(a, 0, stream);
+}
+
 // true: launched (single-workgroup grid, tiled grid or the two passes of non-confocal pairs);
 // false: this render needs the BVH back-end
 bool launch_forward_grid(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
+#ifdef NLOS_ONLY_FEAT0             // ISA studies and syntax checks: one feature set instead of eight (12 s instead of 100 s of hipcc)
+    return grid_dispatch<0>(a, rows_in_lds, stream);
+#else
     switch (feat_of(a.sc, a.sp)) {
         case 0: return grid_dispatch<0>(a, rows_in_lds, stream);
         case 1: return grid_dispatch<1>(a, rows_in_lds, stream);
@@ -1376,6 +1418,7 @@ bool launch_forward_grid(const ForwardArgs& a, int rows_in_lds, hipStream_t stre
         case 6: return grid_dispatch<6>(a, rows_in_lds, stream);
         default: return grid_dispatch<7>(a, rows_in_lds, stream);
     }
+#endif
 }
 
 }  // namespace nlos

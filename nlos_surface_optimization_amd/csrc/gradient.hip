@@ -132,10 +132,13 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
         __syncthreads();
         const int n_live = a.compact ? (int)s_base[nblocks] : n_src;
         const int live_blocks = (n_live + 63) >> 6;
-        const V3 o = ld3(a.src.origin + 3 * (size_t)l);
-        const V3 on = ld3(a.src.normal + 3 * (size_t)l);
-        const V3 ob = NC ? ld3(a.src.sensor + 3 * (size_t)l) : o;
-        const V3 onb = NC ? ld3(a.src.sensor_normal + 3 * (size_t)l) : on;
+        // measurement l: source l, pair l, or -- pass 2 of the L x S product -- the pair (laser l / S, sensor l % S)
+        const size_t la = (NC && a.src.n_sensors > 0) ? (size_t)(l / a.src.n_sensors) : (size_t)l;
+        const size_t lb_ = (NC && a.src.n_sensors > 0) ? (size_t)(l % a.src.n_sensors) : (size_t)l;
+        const V3 o = ld3(a.src.origin + 3 * la);
+        const V3 on = ld3(a.src.normal + 3 * la);
+        const V3 ob = NC ? ld3(a.src.sensor + 3 * lb_) : o;
+        const V3 onb = NC ? ld3(a.src.sensor_normal + 3 * lb_) : on;
         const uint64_t lg = (uint64_t)(a.src.source_offset + (long long)l * a.src.source_stride);
 
         for (;;) {
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                     }
                     Geo g;
                     float t_self;
-                    if (!sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, a.sp.lb, a.sp.ub,
+                    if (!sample_geo<FEAT, true>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, a.sp.lb, a.sp.ub,
                                           a.sc.vertex_normal, a.sc.albedo, g, t_self))
                         continue;   // cannot happen: pass 1 accepted this sample with the same arithmetic
                     const double twoh = (double)(2.0f * g.h);
@@ -384,8 +387,11 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
             Face f;
             Tri tr;
             load_face_tri<FEAT | FEAT_VN>(a.sc, j, f, tr);    // vertices, ids, and the per-face constants the scene build evaluated
-            const V3 o = ld3(a.src.origin + 3 * (size_t)l);
-            const V3 on = ld3(a.src.normal + 3 * (size_t)l);
+            // (pass 2 of the L x S product: measurement l is the pair (laser l / S, sensor l % S))
+            const size_t la = (NC && a.src.n_sensors > 0) ? (size_t)(l / a.src.n_sensors) : (size_t)l;
+            const size_t lsn = (NC && a.src.n_sensors > 0) ? (size_t)(l % a.src.n_sensors) : (size_t)l;
+            const V3 o = ld3(a.src.origin + 3 * la);
+            const V3 on = ld3(a.src.normal + 3 * la);
             const uint64_t kbase = ((uint64_t)(a.src.source_offset + (long long)l * a.src.source_stride) * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
             const uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
             double acc[9];
@@ -406,18 +412,18 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
                         // row N: two legs, d(d1 + d2)/dp = dirA + dirB; P1 carries the confocal factor 2
                         GeoNC gc;
                         float tA, tB;
-                        if (!sample_geo_nc<FEAT>(f, tr, o, ld3(a.src.sensor + 3 * (size_t)l), a.sp.seed,
+                        if (!sample_geo_nc<FEAT>(f, tr, o, ld3(a.src.sensor + 3 * lsn), a.sp.seed,
                                                  kbase + (uint64_t)((wi << 5) + bit), a.sp.lb, a.sp.ub, a.sc.vertex_normal,
                                                  a.sc.albedo, gc, tA, tB))
                             continue;
-                        grad_vectors_nc<FEAT>(f, gc, on, ld3(a.src.sensor_normal + 3 * (size_t)l), a.normal_term, a.sp.ggx_alpha, gv);
+                        grad_vectors_nc<FEAT>(f, gc, on, ld3(a.src.sensor_normal + 3 * lsn), a.normal_term, a.sp.ggx_alpha, gv);
                         di = ((gc.dirA + gc.dirB) * 0.5f) * gv.inten_f;
                         bw[0] = gc.u; bw[1] = gc.v; bw[2] = gc.w;
                         twoh = (double)(gc.d1 + gc.d2);
                     } else {
                         Geo g;
                         float t_self;
-                        if (!sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)((wi << 5) + bit), a.sp.lb, a.sp.ub,
+                        if (!sample_geo<FEAT, true>(f, tr, o, a.sp.seed, kbase + (uint64_t)((wi << 5) + bit), a.sp.lb, a.sp.ub,
                                               a.sc.vertex_normal, a.sc.albedo, g, t_self))
                             continue;
                         grad_vectors<FEAT>(f, g, on, a.normal_term, a.v1_style, a.sp.ggx_alpha, gv);

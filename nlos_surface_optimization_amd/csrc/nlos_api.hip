@@ -104,6 +104,7 @@ struct nlos_ctx {
     DevBuf vis, diff, fine, taps, rows_tmp, grad_tmp, live;
     DevBuf reg_normal, reg_area, reg_owner;
     DevBuf vis2, tile_list, tile_count, cov;
+    DevBuf prod_rec, prod_pairs;     // the product of row N: per-wall-point records; enumerated pairs of the fallback
     int tap_refine = -1, tap_sigma = -1; float tap_res = -1.0f; int tap_kind = -1;
     // host-pointer path staging
     DevBuf io[16];
@@ -372,7 +373,7 @@ void nlos_ctx_destroy(nlos_ctx* c) {
     DeviceGuard g(c->device);
     DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                      &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag, &c->vis_items};
+                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag, &c->vis_items, &c->prod_rec, &c->prod_pairs};
     for (DevBuf* b : all) b->release();
     for (DevBuf& b : c->io) b.release();
     for (hipEvent_t& e : c->ring) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
@@ -385,7 +386,7 @@ int64_t nlos_ctx_scratch_bytes(const nlos_ctx* c) {
     if (!c) return 0;
     const DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                            &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag, &c->vis_items};
+                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag, &c->vis_items, &c->prod_rec, &c->prod_pairs};
     int64_t s = 0;
     for (const DevBuf* b : all) s += (int64_t)b->cap;
     for (const DevBuf& b : c->io) s += (int64_t)b.cap;
@@ -454,7 +455,10 @@ void nlos_render_args_init(nlos_render_args* a) {
     a->vertex_num = -1;
 }
 
+static int render_product(nlos_ctx* c, const nlos_render_args* a, void* stream);
+
 int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
+    if (c && a && a->n_sensors > 0) return render_product(c, a, stream);
     if (!c || !a) return fail(NLOS_ERR_ARG, "nlos_render: NULL ctx/args");
     if (a->F <= 0 || a->V <= 0) return fail(NLOS_ERR_ARG, "nlos_render: empty mesh");
     if (a->L < 0) return fail(NLOS_ERR_ARG, "nlos_render: negative source count");
@@ -531,7 +535,8 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     nlos::SourceView src;
     src.origin = a->origin; src.normal = a->normal; src.L = L;
     src.source_offset = a->source_offset; src.total_sources = a->total_sources;
-    src.source_stride = a->source_stride > 1 ? a->source_stride : 1;
+    src.source_stride = a->shared_samples ? 0 : (a->source_stride > 1 ? a->source_stride : 1);
+    src.n_sensors = 0;
     src.sensor = a->sensor; src.sensor_normal = a->sensor ? a->sensor_normal : nullptr;
 
     nlos::SampleParams sp;
@@ -563,6 +568,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.intensity = a->intensity; fa.mode_intensity = mode == NLOS_MODE_INTENSITY ? 1 : 0;
     fa.force_bvh = (a->force_bvh == 1 || v1_point) ? 1 : 0;
     fa.dbg = nullptr;
+    fa.rec_d = fa.rec_ff = nullptr;
     fa.live = nullptr;
     fa.cov = nullptr;
     fa.tile_list = nullptr;
@@ -632,7 +638,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         fa.vis2 = c->vis2.as<uint32_t>();
     }
     nlos_ctx::VisKey key;
-    key.L = L; key.F = nF; key.V = nV; key.spt = spt; key.off = a->source_offset; key.stride = a->source_stride > 1 ? a->source_stride : 1; key.seed = a->seed;
+    key.L = L; key.F = nF; key.V = nV; key.spt = spt; key.off = a->source_offset; key.stride = a->shared_samples ? 0 : (a->source_stride > 1 ? a->source_stride : 1); key.seed = a->seed;
     key.lb = lb; key.ub = ub;
     key.feat = (vn ? 1 : 0) | (alb ? 2 : 0) | (sp.use_ggx ? 4 : 0) | (sp.clamp ? 8 : 0) | (a->sensor ? 16 : 0);
     key.mesh_gen = c->mesh_gen;
@@ -656,7 +662,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         // item masks beside the words: the launcher that runs decides which of the two pass 1 records (the grid kernel
         // of confocal renders takes the masks; pairs, tiled grid and BVH back-end keep the per-face words)
         static const bool items_enabled = [] { const char* e = std::getenv("NLOS_VIS_ITEMS"); return !e || std::atoi(e) != 0; }();
-        if (items_enabled && !skip_pass1 && spt <= 32 && !a->sensor && fa.live && !fa.tile_list) {
+        if (items_enabled && !skip_pass1 && spt <= 32 && fa.live && !fa.tile_list) {
             const int stride = (int)(((size_t)nF * spt + 63) / 64) + 2;
             rc = c->vis_items.ensure(sizeof(unsigned long long) * (size_t)L * stride + 16);
             if (rc) return rc;
@@ -863,6 +869,175 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         }
         ga.lds_grad = 1;          // allowed; launch_gradient decides from the LDS the mesh needs
         ga.compact = 0;
+        nlos::launch_gradient(ga, st);
+    }
+    mark(c, 4, st);
+    c->ev_valid = c->timing;
+    c->path.gradient_kernel = note.gradient_kernel;
+    if (note.err != hipSuccess)
+        return fail(NLOS_ERR_HIP, std::string(note.err_what ? note.err_what : "launch") + ": " + hipGetErrorString(note.err));
+    HIP_TRY(hipGetLastError());
+    return NLOS_OK;
+}
+
+// Row N as the product of a laser set and a sensor set (include/nlos_hip.h, nlos_render_args.n_sensors).
+//   fast path  (face normals, no albedo, Lambertian, single-workgroup grid, spt <= 32, unrefined rows that fit LDS):
+//              one record pass per wall point (k_forward_grid<0, 3>: leg length + form factor of every sample the point
+//              sees), one combine kernel over the pairs (rows + accepted-sample words), then residual and the pair
+//              gradient kernel over the L x S measurements -- O(L + S) grid passes instead of 2 L S;
+//   otherwise  the pairs are enumerated into scratch arrays and rendered by the pair path on shared samples.
+// Both are the same function of the inputs (the product is defined as its pairs).
+static int render_product(nlos_ctx* c, const nlos_render_args* a, void* stream) {
+    if (a->L < 0) return fail(NLOS_ERR_ARG, "nlos_render (product): negative laser count");
+    if (!a->sensor || !a->sensor_normal || (a->L > 0 && (!a->origin || !a->normal)))
+        return fail(NLOS_ERR_ARG, "nlos_render (product): laser / sensor arrays are NULL");
+    if (a->mode != NLOS_MODE_TRANSIENT && a->mode != NLOS_MODE_GRADIENT)
+        return fail(NLOS_ERR_ARG, "nlos_render (product): TRANSIENT and GRADIENT modes only");
+    if (a->residual || a->reuse_visibility || a->keep_visibility || a->jitter_weight || !a->clamp)
+        return fail(NLOS_ERR_ARG, "nlos_render (product): residual / visibility reuse / jitter / unclamped form factors are not offered");
+    if (a->F <= 0 || a->V <= 0 || !a->vertices || !a->faces) return fail(NLOS_ERR_ARG, "nlos_render: empty mesh");
+    if (a->num_samples <= 0) return fail(NLOS_ERR_ARG, "nlos_render: num_samples must be positive");
+    DeviceGuard guard(c->device);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int La = a->L, Sb = a->n_sensors, nF = a->F, nV = a->V;
+    if ((long long)La * Sb > (1LL << 30)) return fail(NLOS_ERR_ARG, "nlos_render (product): too many pairs");
+    const int P = La * Sb;
+    const float lb = a->lower_bound, ub = a->upper_bound, res = a->resolution;
+    const int T = nlos_num_bins(lb, ub, res);
+    if (T <= 0) return fail(NLOS_ERR_ARG, "nlos_render: zero bins");
+    const int spt = 1 + ((a->num_samples - 1) / nF);
+    const bool grad = a->mode == NLOS_MODE_GRADIENT;
+    const int fwd_refine = grad ? (a->sigma_bin < 5 ? 1 : a->refine_scale) : a->refine_scale;
+    static const int tile_threshold = [] { const char* e = std::getenv("NLOS_TILE_THRESHOLD"); return e ? std::atoi(e) : 6200; }();
+    const int Ltot = (a->total_sources > 0 ? a->total_sources : La) * Sb;      // measurements the gradient is averaged over
+    const bool fast = !a->product_pairs && !a->vertex_normal && !a->albedo && !a->use_ggx && a->force_bvh == 0 && nF >= 64 &&
+                      nF <= tile_threshold && spt <= 32 && fwd_refine == 1 && (size_t)T * sizeof(double) <= 48 * 1024 && La > 0 &&
+                      a->source_stride <= 1;
+    // ---- the enumerated pairs, on shared samples (what the product is defined as)
+    auto as_pairs = [&]() -> int {
+        if (P == 0) return fail(NLOS_ERR_ARG, "nlos_render (product): no pairs");
+        int rcp = c->prod_pairs.ensure(sizeof(float) * 12 * (size_t)P + 64);
+        if (rcp) return rcp;
+        float* pl = c->prod_pairs.as<float>();
+        float *pln = pl + 3 * (size_t)P, *ps = pl + 6 * (size_t)P, *psn = pl + 9 * (size_t)P;
+        nlos::launch_expand_pairs(a->origin, a->normal, a->sensor, a->sensor_normal, La, Sb, pl, pln, ps, psn, st);
+        nlos_render_args b = *a;
+        b.n_sensors = 0; b.product_pairs = 0;
+        b.origin = pl; b.normal = pln; b.sensor = ps; b.sensor_normal = psn;
+        b.L = P; b.shared_samples = 1; b.source_stride = 0; b.total_sources = Ltot;
+        return nlos_render(c, &b, stream);
+    };
+    if (!fast) return as_pairs();
+
+    if (!a->transient) return fail(NLOS_ERR_ARG, "nlos_render: transient is NULL");
+    if (grad && (!a->data || !a->gradient)) return fail(NLOS_ERR_ARG, "nlos_render: gradient modes need data and a gradient output");
+    int rc = check_status(c, false);
+    if (rc) return rc;
+    nlos::LaunchNote note;
+    struct NoteScope { NoteScope(nlos::LaunchNote* n) { nlos::tl_note = n; } ~NoteScope() { nlos::tl_note = nullptr; } } note_scope(&note);
+    std::memset(&c->path, 0, sizeof(c->path));
+    c->path.workgroups = c->path.coarsened = c->path.big_lds = c->path.bvh_queries = -1;
+    c->path_retry_workgroups = 0;
+    mark(c, 0, st);
+    static const bool lazy_enabled = [] { const char* e = std::getenv("NLOS_LAZY_TREE"); return !e || std::atoi(e) != 0; }();
+    rc = ensure_bvh(c, a->vertices, nV, a->faces, nF, a->reuse_bvh != 0, a->mesh_generation, st, lazy_enabled);
+    if (rc) return rc;
+    if (!c->tree_complete) note.lazy_build = &c->lazy_args;
+    mark(c, 1, st);
+    nlos::SceneView sc = scene_view(c, nF, nV, nullptr, nullptr);
+
+    // ---- record pass: lasers, then sensors (the same records serve both roles when the two sets are one array)
+    const bool same_set = a->sensor == a->origin && a->sensor_normal == a->normal && Sb == La;
+    const int W = same_set ? La : La + Sb;
+    const size_t R = (size_t)nF * (size_t)spt;
+    const int Wmax = La > Sb ? La : Sb;
+    rc = c->prod_rec.ensure(sizeof(float) * 2 * (size_t)W * R + 64);
+    if (!rc) rc = c->live.ensure(sizeof(uint16_t) * (size_t)Wmax * nF + 16);
+    if (!rc) rc = c->cov.ensure(sizeof(uint16_t) * (size_t)Wmax * nF + 16);
+    if (!rc) rc = c->tile_count.ensure(sizeof(int) * (size_t)Wmax + 16);
+    if (rc) return rc;
+    float* rec_d = c->prod_rec.as<float>();
+    float* rec_ff = rec_d + (size_t)W * R;
+    HIP_TRY(hipMemsetAsync(rec_ff, 0, sizeof(float) * (size_t)W * R, st));      // ff = 0: not seen (d is read only where ff > 0)
+    nlos::ForwardArgs fa;
+    std::memset(&fa, 0, sizeof(fa));
+    fa.sc = sc;
+    fa.sp.seed = a->seed; fa.sp.spt = spt; fa.sp.lb = lb; fa.sp.ub = ub; fa.sp.res = res; fa.sp.nbins = T;
+    fa.sp.clamp = 1; fa.sp.use_ggx = 0; fa.sp.ggx_alpha = 0.0f; fa.sp.sampled_point = 0;
+    fa.src.source_offset = a->source_offset; fa.src.source_stride = 0; fa.src.total_sources = Ltot; fa.src.n_sensors = 0;
+    fa.vis_words = 1;
+    fa.live = c->live.as<uint16_t>(); fa.cov = c->cov.as<uint16_t>(); fa.retry = c->tile_count.as<int>();
+    bool ok_launch = true;
+    for (int side = 0; side < (same_set ? 1 : 2) && ok_launch; ++side) {
+        fa.src.origin = side ? a->sensor : a->origin;
+        fa.src.normal = side ? a->sensor_normal : a->normal;
+        fa.src.L = side ? Sb : La;
+        fa.rec_d = rec_d + (side ? (size_t)La * R : 0);
+        fa.rec_ff = rec_ff + (side ? (size_t)La * R : 0);
+        fa.need_tree = c->tree_complete || note.tree_built ? nullptr : c->lazy_flag.as<int>();
+        ok_launch = nlos::launch_forward_record(fa, st);
+        if (note.tree_built) c->tree_complete = true;
+    }
+    if (!ok_launch) return as_pairs();      // (the grid kernel's LDS does not hold this scene: nothing was launched)
+    c->path.backend = note.backend; c->path.reason = note.reason; c->path.grid_R = note.grid_R;
+    c->path.tiles = 1; c->path.chunks = 1; c->path.rows_in_lds = 1;
+    c->path_retry_workgroups = note.retry_workgroups;
+    // the visibility cache of the context now describes nothing a later reuse_visibility could ask for
+    c->vis_key = nlos_ctx::VisKey();
+    c->vis_gen = 0;
+
+    // ---- combine: rows [La, Sb, T] (+ the accepted-sample words of every pair for pass 2)
+    nlos::ProductArgs pa;
+    pa.sc = sc;
+    pa.d_a = rec_d; pa.ff_a = rec_ff;
+    pa.d_b = same_set ? rec_d : rec_d + (size_t)La * R;
+    pa.ff_b = same_set ? rec_ff : rec_ff + (size_t)La * R;
+    pa.La = La; pa.Sb = Sb; pa.spt = spt; pa.nbins = T; pa.lb = lb; pa.ub = ub; pa.res = res;
+    pa.rows = a->transient;
+    pa.vis = nullptr;
+    if (grad) {
+        rc = c->vis.ensure(sizeof(uint32_t) * (size_t)P * nF + 16);
+        if (rc) return rc;
+        pa.vis = c->vis.as<uint32_t>();
+    }
+    nlos::launch_product_combine(pa, st);
+    mark(c, 2, st);
+
+    // ---- residual + pathlengths, then pass 2 over the pairs
+    nlos::ResidualArgs ra;
+    std::memset(&ra, 0, sizeof(ra));
+    ra.pathlengths = a->pathlengths; ra.T = T; ra.lb = lb; ra.res = res;
+    if (grad) {
+        rc = c->diff.ensure(sizeof(double) * (size_t)P * T + 16);
+        if (rc) return rc;
+        ra.data = a->data; ra.weight = a->weight; ra.transient = a->transient; ra.diff = c->diff.as<double>();
+        ra.L = P; ra.loss_test = a->loss_test;
+        if (a->zero_gradient) { ra.zero = a->gradient; ra.zero_n = 3 * (size_t)nV; }
+    }
+    if (grad || a->pathlengths) nlos::launch_residual(ra, st);
+    mark(c, 3, st);
+    if (grad) {
+        int K = 0;
+        rc = ensure_taps(c, 0, a->refine_scale, a->sigma_bin, res, st, &K);
+        if (rc) return rc;
+        nlos::GradientArgs ga;
+        std::memset(&ga, 0, sizeof(ga));
+        ga.sc = sc; ga.sp = fa.sp;
+        ga.src.origin = a->origin; ga.src.normal = a->normal; ga.src.sensor = a->sensor; ga.src.sensor_normal = a->sensor_normal;
+        ga.src.L = P; ga.src.n_sensors = Sb; ga.src.source_offset = a->source_offset; ga.src.source_stride = 0;
+        ga.src.total_sources = Ltot;
+        ga.vis = c->vis.as<uint32_t>(); ga.vis_words = 1; ga.vis_scratch = c->vis.as<uint32_t>();
+        ga.tap_w = c->taps.as<double>(); ga.tap_delta = ga.tap_w + K; ga.tap_g = ga.tap_w + 2 * K;
+        ga.tap_p0 = ga.tap_w + 3 * K; ga.tap_p1 = ga.tap_w + 4 * K + 1; ga.tap_pw = ga.tap_w + 5 * K + 2;
+        ga.K = K;
+        ga.two_rs = 2 * a->refine_scale * a->sigma_bin;
+        ga.r_over_res = (double)a->refine_scale / (double)res;
+        ga.refine = a->refine_scale;
+        ga.diff = c->diff.as<double>();
+        ga.mode = 0;
+        ga.normal_term = a->normal_term < 0 ? 0 : (a->normal_term ? 1 : 0);      // (face normals: the reference rule gives 0)
+        ga.out = a->gradient;
+        ga.lds_grad = 1;
         nlos::launch_gradient(ga, st);
     }
     mark(c, 4, st);
@@ -1086,6 +1261,7 @@ struct HostRender {
     int refine = 1, sigma_bin = 1, testing_flag = 0, loss_test = 0, use_ggx = 0, clamp = 1, w_width = 0, vertex_num = -1;
     int sampled_point = 0;
     float alpha = 0;
+    int n_sensors = 0;          // > 0: the L x S product (sensor arrays of n_sensors rows, rows [L, n_sensors, T])
 };
 
 int host_render(const HostRender& h) {
@@ -1106,8 +1282,11 @@ int host_render(const HostRender& h) {
     a.mode = h.mode;
     a.origin = hc.up(h.origin, 3 * (size_t)h.L);
     a.normal = hc.up(h.normal, 3 * (size_t)h.L);
-    a.sensor = hc.up(h.sensor, 3 * (size_t)h.L);
-    a.sensor_normal = hc.up(h.sensor_normal, 3 * (size_t)h.L);
+    const size_t n_sens = h.n_sensors > 0 ? (size_t)h.n_sensors : (size_t)h.L;      // sensor points
+    const size_t n_meas = h.n_sensors > 0 ? (size_t)h.L * (size_t)h.n_sensors : (size_t)h.L;   // rows of transient / data / weight
+    a.n_sensors = h.n_sensors;
+    a.sensor = hc.up(h.sensor, 3 * n_sens);
+    a.sensor_normal = hc.up(h.sensor_normal, 3 * n_sens);
     a.jitter_weight = hc.up(h.jitter_weight, (size_t)h.jitter_length);
     a.jitter_grad = hc.up(h.jitter_grad, (size_t)h.jitter_length);
     a.jitter_offset = h.jitter_offset; a.jitter_length = h.jitter_length;
@@ -1120,9 +1299,9 @@ int host_render(const HostRender& h) {
     a.lower_bound = h.lb; a.upper_bound = h.ub; a.resolution = h.res;
     a.refine_scale = h.refine; a.sigma_bin = h.sigma_bin;
     a.seed = g_default_seed;
-    a.data = hc.up(h.data, (size_t)h.L * T);
-    a.weight = hc.up(h.weight, (size_t)h.L * T);
-    a.transient = hc.inout(h.transient, (size_t)h.L * T, false);
+    a.data = hc.up(h.data, n_meas * T);
+    a.weight = hc.up(h.weight, n_meas * T);
+    a.transient = hc.inout(h.transient, n_meas * T, false);
     a.pathlengths = hc.inout(h.pathlengths, (size_t)T, false);
     if (h.mode == NLOS_MODE_VERTEX_GRADIENT) a.gradient = hc.inout(h.gradient, 3 * (size_t)T, true);
     else a.gradient = hc.inout(h.gradient, 3 * (size_t)h.V, h.mode != NLOS_MODE_GRADIENT_V1);
@@ -1190,6 +1369,40 @@ int nlos_nonconfocal_render_gradient(double* data, double* weight, float* laser,
     h.origin = laser; h.normal = laserNormal; h.sensor = sensor; h.sensor_normal = sensorNormal; h.L = numPairs;
     h.vertices = vertices; h.V = numVertices;
     h.vnormal = vertexNormal; h.albedo = vertexAlbedo; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.transient = transient; h.pathlengths = pathlengths; h.gradient = gradient;
+    h.refine = refine_scale; h.sigma_bin = sigma_bin; h.testing_flag = testing_flag; h.loss_test = loss_test;
+    return host_render(h);
+}
+
+int nlos_nonconfocal_product_render_transient(float* laser, float* laserNormal, int numLasers, float* sensor,
+                                              float* sensorNormal, int numSensors, float* vertices, int numVertices,
+                                              int* triangles, int numTriangles, int numSamples, float lowerBound,
+                                              float upperBound, float resolution, double* transient, double* pathlengths) {
+    if (numSensors <= 0 || !sensor || !sensorNormal) return fail(NLOS_ERR_ARG, "non-confocal product: sensor arrays are NULL or empty");
+    HostRender h;
+    h.mode = NLOS_MODE_TRANSIENT;
+    h.origin = laser; h.normal = laserNormal; h.sensor = sensor; h.sensor_normal = sensorNormal; h.L = numLasers;
+    h.n_sensors = numSensors;
+    h.vertices = vertices; h.V = numVertices; h.faces = triangles; h.F = numTriangles;
+    h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
+    h.transient = transient; h.pathlengths = pathlengths;
+    return host_render(h);
+}
+
+int nlos_nonconfocal_product_render_gradient(double* data, double* weight, float* laser, float* laserNormal, int numLasers,
+                                             float* sensor, float* sensorNormal, int numSensors, float* vertices,
+                                             int numVertices, int* triangles, int numTriangles, int numSamples,
+                                             float lowerBound, float upperBound, float resolution, double* transient,
+                                             double* pathlengths, double* gradient, int refine_scale, int sigma_bin,
+                                             int testing_flag, int loss_test) {
+    if (numSensors <= 0 || !sensor || !sensorNormal) return fail(NLOS_ERR_ARG, "non-confocal product: sensor arrays are NULL or empty");
+    HostRender h;
+    h.mode = NLOS_MODE_GRADIENT;
+    h.data = data; h.weight = weight;
+    h.origin = laser; h.normal = laserNormal; h.sensor = sensor; h.sensor_normal = sensorNormal; h.L = numLasers;
+    h.n_sensors = numSensors;
+    h.vertices = vertices; h.V = numVertices; h.faces = triangles; h.F = numTriangles;
     h.num_samples = numSamples; h.lb = lowerBound; h.ub = upperBound; h.res = resolution;
     h.transient = transient; h.pathlengths = pathlengths; h.gradient = gradient;
     h.refine = refine_scale; h.sigma_bin = sigma_bin; h.testing_flag = testing_flag; h.loss_test = loss_test;

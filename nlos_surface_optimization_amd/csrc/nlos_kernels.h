@@ -72,7 +72,8 @@ struct SourceView {
     const float* normal;     // [L,3]
     int L;
     long long source_offset; // global index of origin[0]
-    int source_stride;       // global index of origin[l] = source_offset + l * source_stride (>= 1)
+    int source_stride;       // global index of origin[l] = source_offset + l * source_stride (0: every source draws the same samples)
+    int n_sensors;           // > 0 (pass 2 of the product): measurement l is the pair (origin[l / n_sensors], sensor[l % n_sensors])
     int total_sources;       // for 1/L
     // row N (non-confocal pairs): sensor point / wall normal of pair l; null = confocal
     const float* sensor;     // [L,3] or null
@@ -117,10 +118,30 @@ struct ForwardArgs {
     int* tile_count;         // [L * tiles] subset sizes (may exceed tile_cap: overflow), filled by k_tile_bin
     int tiles_x, tiles_y, tile_cap;
     int* retry;              // [workgroups] flags of the big-LDS second launch (grid kernels) or null
+    // record pass of the product (row N as L x S): per wall point and sample r = sorted face slot * spt + s, the path
+    // length of the leg and its clamped form factor, 0 where the sample is not seen from that wall point
+    float* rec_d;            // [L, F * spt] or null
+    float* rec_ff;           // [L, F * spt]
     int* need_tree;          // lazy scene build: raised by first-launch workgroups that need the BVH query (they then leave it to
                              // the second launch, in front of which the tree is completed); null = the tree exists
 };
 void launch_forward(const ForwardArgs& a, hipStream_t stream);
+// record pass of the product (single-workgroup grid, face normals, Lambertian); false: not available for this scene
+bool launch_forward_record(const ForwardArgs& a, hipStream_t stream);
+// combine kernel of the product: rows [La * Sb, T] (overwritten) and, if `vis` is given, the accepted-sample words
+// [La * Sb, 1, F] pass 2 reads
+struct ProductArgs {
+    SceneView sc;
+    const float* d_a; const float* ff_a;   // laser records [La, F * spt]
+    const float* d_b; const float* ff_b;   // sensor records [Sb, F * spt]
+    int La, Sb, spt, nbins;
+    float lb, ub, res;
+    double* rows;
+    uint32_t* vis;
+};
+void launch_product_combine(const ProductArgs& a, hipStream_t stream);
+void launch_expand_pairs(const float* laser, const float* lnormal, const float* sensor, const float* snormal, int La, int Sb,
+                         float* out_l, float* out_ln, float* out_s, float* out_sn, hipStream_t stream);
 // the two back-ends behind launch_forward (forward_grid.hip returns false when the BVH back-end is needed)
 bool launch_forward_grid(const ForwardArgs& a, int rows_in_lds, hipStream_t stream);
 void launch_forward_bvh(const ForwardArgs& a, int rows_in_lds, hipStream_t stream);

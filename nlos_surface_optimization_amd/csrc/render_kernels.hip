@@ -132,6 +132,66 @@ __global__ __launch_bounds__(256) void k_bary_to_world(const float* V, const int
         out[3 * (size_t)i + k] = (1 - u - v) * V[3 * a + k] + u * V[3 * b + k] + v * V[3 * c + k];
 }
 
+// ------------------------------------------------------------ row N as a product
+// Combine kernel of the L x S product (include/nlos_hip.h, nlos_render_args.n_sensors): one workgroup per (laser i,
+// sensor j), its row in LDS.  The record pass (forward_grid.hip, NCM = 3) left, per wall point and sample r = sorted face
+// slot * spt + s, the leg's path length and clamped form factor (0: not seen from there); a pair accepts the sample iff
+// both legs did and d1 + d2 lies in the window -- the expressions of the pair kernels (k_forward_grid<FEAT, 2>,
+// sample_geo_nc) term for term: val = (area ffa) ffb, bin = floor(((d1 + d2) - lb) / res), (double)val / spt.
+// One lane per face, its spt strata in turn; the accepted-sample word of (pair, face) is what pass 2 reads.
+__global__ __launch_bounds__(256) void k_product_combine(ProductArgs a) {
+    extern __shared__ double s_prow[];
+    const int pair = blockIdx.x;
+    const int i = pair / a.Sb, j = pair - i * a.Sb;
+    const int F = a.sc.F, spt = a.spt, nbins = a.nbins;
+    for (int b = threadIdx.x; b < nbins; b += blockDim.x) s_prow[b] = 0.0;
+    __syncthreads();
+    const size_t R = (size_t)F * (size_t)spt;
+    const float* __restrict__ dA = a.d_a + (size_t)i * R;
+    const float* __restrict__ fA = a.ff_a + (size_t)i * R;
+    const float* __restrict__ dB = a.d_b + (size_t)j * R;
+    const float* __restrict__ fB = a.ff_b + (size_t)j * R;
+    const double inv_spt = 1.0 / (double)spt;
+    for (int jf = threadIdx.x; jf < F; jf += blockDim.x) {
+        uint32_t word = 0u;
+        const size_t r0 = (size_t)jf * (size_t)spt;
+        float area = 0.0f;
+        for (int s = 0; s < spt; ++s) {
+            const float ffa = fA[r0 + s];
+            if (!(ffa > 0.0f)) continue;
+            const float ffb = fB[r0 + s];
+            if (!(ffb > 0.0f)) continue;
+            const float d1 = dA[r0 + s], d2 = dB[r0 + s];
+            const float tot = d1 + d2;
+            if (!((tot <= a.ub) && (tot >= a.lb))) continue;
+            word |= 1u << s;
+            if (area == 0.0f) area = a.sc.tris[kTriStride * jf + 3].z;
+            const int bin = (int)floorf((tot - a.lb) / a.res);
+            if (bin < 0 || bin >= nbins) continue;
+            const float val = area * ffa * ffb;
+            lds_add_f64(&s_prow[bin], (double)val * inv_spt);
+        }
+        if (a.vis) a.vis[(size_t)pair * F + jf] = word;
+    }
+    __syncthreads();
+    double* row = a.rows + (size_t)pair * nbins;
+    for (int b = threadIdx.x; b < nbins; b += blockDim.x) row[b] = s_prow[b];
+}
+
+// the enumerated pairs of a product, for the renders the record pass does not carry: pair p = (laser p / Sb, sensor p % Sb)
+__global__ __launch_bounds__(256) void k_expand_pairs(const float* __restrict__ laser, const float* __restrict__ lnormal,
+                                                      const float* __restrict__ sensor, const float* __restrict__ snormal,
+                                                      int La, int Sb, float* __restrict__ out_l, float* __restrict__ out_ln,
+                                                      float* __restrict__ out_s, float* __restrict__ out_sn) {
+    const size_t n = 3 * (size_t)La * (size_t)Sb;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = k / 3, c = k - 3 * p;
+        const size_t i = p / (size_t)Sb, j = p - i * (size_t)Sb;
+        out_l[k] = laser[3 * i + c]; out_ln[k] = lnormal[3 * i + c];
+        out_s[k] = sensor[3 * j + c]; out_sn[k] = snormal[3 * j + c];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_zero_f64(double* p, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0.0;
@@ -181,6 +241,24 @@ void launch_residual(const ResidualArgs& a, hipStream_t stream) {
     if (a.w_width > 0 && a.L > 0)
         hipLaunchKernelGGL(k_boxfilter, dim3(a.L), dim3(256), 2 * (size_t)a.T * sizeof(double), stream, a.diff, a.T,
                            a.w_width);
+}
+
+void launch_product_combine(const ProductArgs& a, hipStream_t stream) {
+    if (a.La <= 0 || a.Sb <= 0) return;
+    const size_t lds = (size_t)a.nbins * sizeof(double);
+    note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_product_combine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+             "hipFuncSetAttribute(k_product_combine)");
+    hipLaunchKernelGGL(k_product_combine, dim3((unsigned)((size_t)a.La * a.Sb)), dim3(256), lds, stream, a);
+}
+
+void launch_expand_pairs(const float* laser, const float* lnormal, const float* sensor, const float* snormal, int La, int Sb,
+                         float* out_l, float* out_ln, float* out_s, float* out_sn, hipStream_t stream) {
+    const size_t n = 3 * (size_t)La * (size_t)Sb;
+    if (n == 0) return;
+    size_t g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_expand_pairs, dim3((unsigned)g), dim3(256), 0, stream, laser, lnormal, sensor, snormal, La, Sb, out_l, out_ln,
+                       out_s, out_sn);
 }
 
 void launch_intersect(const IntersectArgs& a, hipStream_t stream) {

@@ -120,7 +120,7 @@ class TransientRenderer:
     def _args(self, mode, origin, normal, vertices, faces, num_sample, lower_bound, upper_bound,
               resolution, refine_scale=1, sigma_bin=1, vertex_normal=None, albedo=None,
               source_offset=0, total_sources=0, alpha=None, seed=None, force_bvh=False, source_stride=1,
-              sensor=None, sensor_normal=None, jitter_weight=None, jitter_grad=None, jitter_offset=0):
+              shared_samples=False, sensor=None, sensor_normal=None, jitter_weight=None, jitter_grad=None, jitter_offset=0):
         a = _lib.RenderArgs()
         self._lib.nlos_render_args_init(ctypes.byref(a))
         _want(origin, torch.float32, "origin", 2); _want(normal, torch.float32, "normal", 2)
@@ -133,6 +133,7 @@ class TransientRenderer:
         a.origin, a.normal, a.L = _dptr(origin), _dptr(normal), origin.shape[0]
         a.source_offset, a.total_sources = int(source_offset), int(total_sources)
         a.source_stride = int(source_stride)
+        a.shared_samples = 1 if shared_samples else 0
         a.vertices, a.V = _dptr(vertices), vertices.shape[0]
         a.faces, a.F = _dptr(faces), faces.shape[0]
         a.vertex_normal, a.albedo = _dptr(vertex_normal), _dptr(albedo)
@@ -218,6 +219,46 @@ class TransientRenderer:
         a.mesh_generation, a.visibility_generation = int(mesh_generation), int(visibility_generation)
         self._run(a, (origin, normal, vertices, faces, vertex_normal, albedo, data, weight, residual))
         return transient, gradient, path
+
+    def render_product(self, laser, laser_normal, sensor, sensor_normal, vertices, faces, num_sample, lower_bound,
+                       upper_bound, resolution, data=None, weight=None, refine_scale=None, sigma_bin=1, testing_flag=1,
+                       loss_flag=0, gradient=None, zero_gradient=False, pairs=False, seed=None, total_lasers=0,
+                       out=None):
+        """Row N as a product (include/nlos_hip.h, nlos_render_args.n_sensors): every (laser[i], sensor[j]) combination on
+        sample points shared by all wall points.  Returns (transient [L, S, T] f64, gradient [V, 3] f64 or None,
+        pathlengths); with `data` ([L, S, T]; `weight` likewise, default 1) the vertex gradient of
+        sum w (data - T)^2 / (L S) is computed (accumulated into `gradient` if given).  pairs=True renders the enumerated
+        pairs instead of the record + combine kernels (the definition; same results)."""
+        grad = data is not None
+        if refine_scale is None:
+            refine_scale = 10 if grad else 1
+        a = self._args(_lib.MODE_GRADIENT if grad else _lib.MODE_TRANSIENT, laser, laser_normal, vertices, faces, num_sample,
+                       lower_bound, upper_bound, resolution, refine_scale, sigma_bin, seed=seed, total_sources=total_lasers)
+        _want(sensor, torch.float32, "sensor", 2); _want(sensor_normal, torch.float32, "sensor_normal", 2)
+        assert sensor.shape[1] == 3 and sensor_normal.shape == sensor.shape and sensor.shape[0] > 0, "sensor/sensor_normal need to be Sx3"
+        L, S, T = laser.shape[0], sensor.shape[0], self.num_bins(lower_bound, upper_bound, resolution)
+        a.sensor, a.sensor_normal, a.n_sensors = _dptr(sensor), _dptr(sensor_normal), S
+        a.product_pairs = 1 if pairs else 0
+        transient = out if out is not None else torch.empty((L, S, T), dtype=torch.float64, device=self.device)
+        assert tuple(transient.shape) == (L, S, T) and transient.is_contiguous(), "transient should be LxSxB"
+        path = torch.empty(T, dtype=torch.float64, device=self.device)
+        a.transient, a.pathlengths = _dptr(transient), _dptr(path)
+        if grad:
+            if weight is None:
+                weight = torch.ones_like(data)
+            _want(data, torch.float64, "data", 3); _want(weight, torch.float64, "weight", 3)
+            assert tuple(data.shape) == (L, S, T) and tuple(weight.shape) == (L, S, T), "data / weight should be LxSxB"
+            if gradient is None:
+                gradient = torch.empty((vertices.shape[0], 3), dtype=torch.float64, device=self.device)
+                zero_gradient = True
+            else:
+                _want(gradient, torch.float64, "gradient", 2)
+                assert tuple(gradient.shape) == (vertices.shape[0], 3), "gradient dimension should be Vx3"
+            a.zero_gradient = 1 if zero_gradient else 0
+            a.data, a.weight, a.gradient = _dptr(data), _dptr(weight), _dptr(gradient)
+            a.testing_flag, a.loss_test = int(testing_flag), int(loss_flag)
+        self._run(a, (laser, laser_normal, sensor, sensor_normal, vertices, faces, data, weight))
+        return transient, (gradient if grad else None), path
 
     def render_gradient_scalar(self, origin, normal, vertices, faces, num_sample, lower_bound, upper_bound,
                                resolution, data, weight, refine_scale=10, sigma_bin=1, loss_flag=0,

@@ -314,3 +314,49 @@ def renderNonConfocalGradient(laser, laser_normal, sensor, sensor_normal, vertic
         lower_bound, upper_bound, resolution, ptr(transient), ptr(pathlengths), ptr(gradient),
         int(refine_scale), int(sigma_bin), int(testing_flag), int(loss_flag))
     _lib.check(rc, "nonconfocal_render_gradient")
+
+
+# ---- row N as a product: every (laser, sensor) combination of two sets of wall points (north_star's L x S x T
+# histogram).  The reference has prototype formulas only (transient_rendering_python/mesh_optimization/rendering.py:739-797);
+# the product is defined as its pairs, rendered on sample points shared by all wall points (include/nlos_hip.h,
+# nlos_render_args.n_sensors).  transient / data / weight are [L, S, B] float64 arrays.
+def _product(laser, laser_normal, sensor, sensor_normal, vertices, faces):
+    L = _common(laser, laser_normal, vertices, faces)
+    f32(sensor, 2, "sensor"); f32(sensor_normal, 2, "sensor_normal")
+    S = sensor.shape[0]
+    assert S > 0 and sensor.shape[1] == 3, "sensor needs to be Sx3"
+    assert sensor_normal.shape[0] == S and sensor_normal.shape[1] == 3, "sensor normal needs to be Sx3"
+    return L, S
+
+
+def renderNonConfocalProductTransient(laser, laser_normal, sensor, sensor_normal, vertices, faces, num_sample,
+                                      lower_bound, upper_bound, resolution, transient, pathlengths):
+    """transient[i, j] = three-bounce histogram of the pair (laser[i], sensor[j]); bins floor((d1 + d2 - lb) / res)."""
+    L, S = _product(laser, laser_normal, sensor, sensor_normal, vertices, faces)
+    numBins = _num_bins(lower_bound, upper_bound, resolution)
+    f64(transient, 3, "transient"); f64(pathlengths, 1, "pathlengths")
+    assert transient.shape == (L, S, numBins), "transient dimension should  be LxSxB   (B = math.ceil((upper_bound-lower_bound)/resolution))"
+    assert pathlengths.shape[0] == numBins, "pathlength dimension should be Bx1 (B = math.ceil((upper_bound-lower_bound)/resolution))"
+    rc = _lib.lib().nlos_nonconfocal_product_render_transient(
+        ptr(laser), ptr(laser_normal), L, ptr(sensor), ptr(sensor_normal), S, ptr(vertices), vertices.shape[0], ptr(faces),
+        faces.shape[0], int(num_sample), lower_bound, upper_bound, resolution, ptr(transient), ptr(pathlengths))
+    _lib.check(rc, "nonconfocal_product_render_transient")
+
+
+def renderNonConfocalProductGradient(laser, laser_normal, sensor, sensor_normal, vertices, faces, num_sample,
+                                     lower_bound, upper_bound, resolution, transient, pathlengths, gradient, data,
+                                     weight, refine_scale, sigma_bin, testing_flag, loss_flag):
+    """Vertex gradient of sum w (data - T)^2 / (L S) over the L x S measurements; accumulated into `gradient`."""
+    L, S = _product(laser, laser_normal, sensor, sensor_normal, vertices, faces)
+    numBins = _num_bins(lower_bound, upper_bound, resolution)
+    f64(transient, 3, "transient"); f64(pathlengths, 1, "pathlengths"); f64(data, 3, "data"); f64(weight, 3, "weight")
+    assert transient.shape == (L, S, numBins), "transient dimension should  be LxSxB   (B = math.ceil((upper_bound-lower_bound)/resolution))"
+    assert pathlengths.shape[0] == numBins, "pathlength dimension should be Bx1 (B = math.ceil((upper_bound-lower_bound)/resolution))"
+    assert data.shape == (L, S, numBins), "data transient dimension should  be LxSxB   (B = math.ceil((upper_bound-lower_bound)/resolution))"
+    assert weight.shape == (L, S, numBins), "weighting should be LxSxB"
+    _check_grad(gradient, vertices)
+    rc = _lib.lib().nlos_nonconfocal_product_render_gradient(
+        ptr(data), ptr(weight), ptr(laser), ptr(laser_normal), L, ptr(sensor), ptr(sensor_normal), S, ptr(vertices),
+        vertices.shape[0], ptr(faces), faces.shape[0], int(num_sample), lower_bound, upper_bound, resolution,
+        ptr(transient), ptr(pathlengths), ptr(gradient), int(refine_scale), int(sigma_bin), int(testing_flag), int(loss_flag))
+    _lib.check(rc, "nonconfocal_product_render_gradient")

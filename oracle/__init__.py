@@ -30,6 +30,7 @@ class Opts(ctypes.Structure):
         ("normal_term", ctypes.c_int32),
         ("clamp", ctypes.c_int32),
         ("source_stride", ctypes.c_int32),
+        ("shared_samples", ctypes.c_int32),
         ("sampled_point", ctypes.c_int32),
     ]
 
@@ -84,7 +85,7 @@ def rule_free():
 
 
 def make_opts(seed=0, source_offset=0, total_sources=0, accel=0, threads=0,
-              ggx_alpha=None, normal_term=-1, clamp=1, sampled_point=0, source_stride=1):
+              ggx_alpha=None, normal_term=-1, clamp=1, sampled_point=0, source_stride=1, shared_samples=0):
     o = Opts()
     o.seed = seed
     o.source_offset = source_offset
@@ -97,6 +98,7 @@ def make_opts(seed=0, source_offset=0, total_sources=0, accel=0, threads=0,
     o.clamp = clamp
     o.sampled_point = sampled_point
     o.source_stride = int(source_stride)
+    o.shared_samples = int(shared_samples)
     return o
 
 
@@ -272,6 +274,28 @@ def render_nonconfocal(laser, laser_normal, sensor, sensor_normal, v, f, num_sam
     if rc:
         raise ValueError("oracle render_nonconfocal failed rc=%d" % rc)
     return transient, (gradient if data is not None else None), path
+
+
+def render_product(laser, laser_normal, sensor, sensor_normal, v, f, num_sample, lb, ub, res, data=None, weight=None,
+                   refine=None, **kw):
+    """Row N as a product: every (laser[i], sensor[j]) combination, on sample points shared by all wall points.  The
+    product is DEFINED as its pairs (include/nlos_hip.h, nlos_render_args.n_sensors), and that is how the checker
+    computes it: the La * Sb pairs are enumerated and handed to the pair renderer with shared_samples = 1.
+    Returns (transient [La, Sb, T], gradient or None, pathlengths); data / weight are [La, Sb, T]; the gradient is
+    normalised by the La * Sb measurements."""
+    laser, laser_normal, sensor, sensor_normal = _f32(laser), _f32(laser_normal), _f32(sensor), _f32(sensor_normal)
+    La, Sb = laser.shape[0], sensor.shape[0]
+    T = num_bins(lb, ub, res)
+    li, sj = np.repeat(np.arange(La), Sb), np.tile(np.arange(Sb), La)
+    if data is not None:
+        data = np.ascontiguousarray(_f64(data).reshape(La * Sb, T))
+        weight = None if weight is None else np.ascontiguousarray(_f64(weight).reshape(La * Sb, T))
+    kw = dict(kw)
+    kw["shared_samples"] = 1
+    kw["refine"] = (1 if data is None else 10) if refine is None else refine     # (forward-only calls smooth when refine > 1)
+    t, g, path = render_nonconfocal(laser[li], laser_normal[li], sensor[sj], sensor_normal[sj], v, f, num_sample, lb, ub, res,
+                                    data=data, weight=weight, **kw)
+    return t.reshape(La, Sb, T), g, path
 
 
 def render_gradient_scalar(origin, normal, v, f, num_sample, lb, ub, res, data, weight,

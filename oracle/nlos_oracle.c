@@ -91,6 +91,7 @@ void nlos_oracle_sample(uint64_t seed, uint64_t k, float *S, float *T) {
 /* global index of source l of this call (source sharding: a contiguous block from source_offset, or every
  * source_stride-th source from it); the sample keys are made of it */
 static inline uint64_t global_source(const nlos_oracle_opts *op, int l) {
+    if (op->shared_samples) return (uint64_t)op->source_offset;
     return (uint64_t)(op->source_offset + (int64_t)l * (op->source_stride > 1 ? op->source_stride : 1));
 }
 

@@ -606,3 +606,41 @@ def test_regularisers_against_finite_differences(orc, bunny):
     e = [vd[f[fi, 2]] - vd[f[fi, 1]], vd[f[fi, 0]] - vd[f[fi, 2]], vd[f[fi, 1]] - vd[f[fi, 0]]][j]
     assert np.allclose(go[i], np.cross(n0[fi], e / 2), rtol=0, atol=1e-7)
     assert not np.allclose(go, ga)
+
+
+def test_product_is_its_pairs_on_shared_samples(orc, mannequin):
+    """Row N as a product (north_star's L x S x T): defined as the enumerated pairs on sample points shared by all wall
+    points (include/nlos_hip.h, nlos_render_args.n_sensors).  With shared samples a wall point's leg does not depend on
+    who it is paired with, so: the diagonal of a set paired with itself is its confocal render, bit for bit; exchanging
+    laser and sensor changes a row only by the fp32 rounding of the resampled hit point; and a plain (unshared)
+    render differs -- the keys really are shared."""
+    v, f = mannequin
+    la = np.array([[0.1, 0, 0], [-0.2, 0.1, 0]], np.float32)
+    sb = np.array([[0.1, 0, 0], [0.3, -0.1, 0], [-0.2, 0.1, 0]], np.float32)
+    n2, n3 = np.tile(np.array([0, 0, 1], np.float32), (2, 1)), np.tile(np.array([0, 0, 1], np.float32), (3, 1))
+    lb, ub, res, ns = 0.0, 2.0, 2.0 ** -9, 4000
+    t, g, path = orc.render_product(la, n2, sb, n3, v, f, ns, lb, ub, res, accel=1, threads=1)
+    assert t.shape == (2, 3, 1024) and g is None and path.shape == (1024,) and (t.sum(axis=2) > 0).all()
+    # pair by pair
+    for i in range(2):
+        for j in range(3):
+            tp, _, _ = orc.render_nonconfocal(la[i:i + 1], n2[:1], sb[j:j + 1], n3[:1], v, f, ns, lb, ub, res, refine=1,
+                                              accel=1, shared_samples=1, threads=1)
+            assert np.array_equal(tp[0], t[i, j])
+    # laser 0 == sensor 0 and laser 1 == sensor 2: the confocal rows of those wall points (shared samples)
+    tc, _ = orc.render_transient(la, n2, v, f, ns, lb, ub, res, accel=1, shared_samples=1, threads=1)
+    assert np.array_equal(t[0, 0], tc[0]) and np.array_equal(t[1, 2], tc[1])
+    tc_plain, _ = orc.render_transient(la, n2, v, f, ns, lb, ub, res, accel=1, threads=1)
+    assert np.array_equal(tc_plain[0], tc[0]) and not np.array_equal(tc_plain[1], tc[1])      # source 0's keys are the shared ones
+    # reciprocity: (laser 0, sensor 2) is (laser 1, sensor 0) with the legs exchanged
+    assert rel_l2(t[0, 2], t[1, 0]) < 1e-6 and not np.array_equal(t[0, 2], t[0, 1])
+    # gradient: normalised by the L * S measurements, the sum of the pairs' contributions
+    data = t * 1.25
+    _, g, _ = orc.render_product(la, n2, sb, n3, v, f, ns, lb, ub, res, data=data, accel=1)
+    acc = np.zeros_like(g)
+    for i in range(2):
+        for j in range(3):
+            _, gp, _ = orc.render_nonconfocal(la[i:i + 1], n2[:1], sb[j:j + 1], n3[:1], v, f, ns, lb, ub, res,
+                                              data=data[i, j][None], accel=1, shared_samples=1, total_sources=6)
+            acc += gp
+    assert np.abs(g).max() > 0 and rel_l2(acc, g) < 1e-12
