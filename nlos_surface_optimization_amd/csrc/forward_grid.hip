@@ -375,6 +375,8 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     const V3 onb = NCM == 2 ? ld3(a.src.sensor_normal + 3 * (size_t)l) : on;
     uint32_t* const visout = NCM == 1 ? a.vis2 : a.vis;
     // item-mask layout of the visibility cache (launcher: single-workgroup grid, confocal; then a.vis == nullptr)
+    // geometry cache for pass 2 (confocal renders that record item masks: its index is the item masks' ray index)
+    float* const geo_l = (!TILED && NCM == 0 && a.geo && a.vis_items) ? a.geo + 3 * (size_t)l * (size_t)a.geo_stride : nullptr;
     // (the laser pass of non-confocal pairs records the pair's accepted samples the same way, round 4)
     unsigned long long* const vitems = (!TILED && (NCM == 0 || NCM == 2) && a.vis_items) ? a.vis_items + (size_t)l * (size_t)a.items_stride : nullptr;
 #ifdef NLOS_FWD_STAMPS
@@ -942,6 +944,15 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     if (FEAT & FEAT_GGX) val = val * ggx_eval(a.sp.ggx_alpha, dot(gg.n, -gg.dir));
                     bin = (int)floorf((2.0f * gg.h - lb) / res);
                     dir = gg.dir;
+                    if (geo_l && ok) {
+                        // what pass 2 needs of this sample, written HERE (before the trace: the three values are dead
+                        // afterwards; an occluded ray's entry is simply never read).  One global_store_dwordx3 per item:
+                        // forward 1.341 -> 1.374 ms, pass 2 0.540 -> 0.447 ms.  (Deferred behind the next item's loads like
+                        // the item mask -- three more registers live across the trace -- it costs more: 1.399 ms;
+                        // profiles/r04_ab_geo_cache.log.)
+                        float* gp = geo_l + 3 * (size_t)r;
+                        gp[0] = gg.h; gp[1] = gg.v; gp[2] = gg.w;
+                    }
                 }
             } else if (NCM == 3) {
                 // record pass of the product (row N as L x S): this wall point's leg of every pair it takes part in --
@@ -1266,6 +1277,7 @@ bool forward_grid_launch(const ForwardArgs& a_in, int rows_in_lds, hipStream_t s
     const bool items = (NCM == 0 || NCM == 2) && b.vis_items && b.vis;
     if (items) b.vis = nullptr;
     else b.vis_items = nullptr;
+    if (!items || NCM != 0) b.geo = nullptr;
     const ForwardArgs& a = b;
     LaunchNote scratch_note;
     LaunchNote& note = tl_note ? *tl_note : scratch_note;

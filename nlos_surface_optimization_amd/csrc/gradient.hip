@@ -43,7 +43,10 @@ __global__ __launch_bounds__(256) void k_items_to_words(const unsigned long long
 #endif
 // NT = 1024: one workgroup per CU with the same sixteen waves, for meshes whose 3V-double accumulator leaves no
 // room for two workgroups of 512 (V > ~2600)
-template <int FEAT, int MODE, bool NC = false, int NT = NLOS_GRAD_NT>
+// GEO: the samples' h and hit barycentrics come from pass 1's geometry cache (confocal vertex gradient on the item-mask
+// layout) instead of being recomputed (hash, two square roots, own-face test); an instance of its own so that the
+// recomputing path keeps its registers
+template <int FEAT, int MODE, bool NC = false, int NT = NLOS_GRAD_NT, bool GEO = false>
 __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) {
     extern __shared__ double s_mem[];       // [ticket (8 B)][diff row T][tap tables 3K+2][grad 3V][masks][bases][live]
     int* s_next = reinterpret_cast<int*>(s_mem);
@@ -90,6 +93,8 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
         // source's bucketed live list (half of the faces), their bits come out of one or two 64-bit item masks
         const unsigned long long* it_l = a.vis_items ? a.vis_items + (size_t)l * (size_t)a.items_stride : nullptr;
         const uint16_t* live_l = a.vis_items ? a.live + (size_t)l * F : nullptr;
+        // pass 1's geometry cache (vertex-gradient modes of confocal renders): h and the hit's barycentrics per ray of the live list
+        const float* geo_l = GEO ? a.geo + 3 * (size_t)l * (size_t)a.geo_stride : nullptr;
         const int n_src = it_l ? (int)it_l[0] : F;
         // faces with at least one accepted sample, compacted in order (pass 1 left the masks)
         for (int b = wave; b < nblocks; b += nwaves) {
@@ -163,10 +168,22 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
 
             for (int wi = 0; wi < n_words; ++wi) {
                 uint32_t word = it_l ? ibits : visp[(size_t)wi * F];
+                // GEO: the record of the NEXT accepted sample is requested one sample ahead (a dependent 12-byte load per
+                // sample in front of its arithmetic left the kernel waiting: 0.558 -> 0.503 ms only, profiles/r04_ab_geo_cache.log)
+                float nh = 0.0f, nv = 0.0f, nw = 0.0f;
+                if (GEO && word) {
+                    const float* gp = geo_l + 3 * ((size_t)e * (size_t)spt + (size_t)(__ffs(word) - 1));
+                    nh = gp[0]; nv = gp[1]; nw = gp[2];
+                }
                 while (word) {
                     const int bit = __ffs(word) - 1;
                     word &= word - 1;
                     const int s = (wi << 5) + bit;
+                    const float ch = nh, cv = nv, cw = nw;
+                    if (GEO && word) {
+                        const float* gp = geo_l + 3 * ((size_t)e * (size_t)spt + (size_t)(__ffs(word) - 1));
+                        nh = gp[0]; nv = gp[1]; nw = gp[2];
+                    }
                     if (NC) {
                         // row N: two legs, d(d1 + d2)/dp = dirA + dirB; P1 carries the confocal factor 2
                         GeoNC gc;
@@ -194,8 +211,10 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                     }
                     Geo g;
                     float t_self;
-                    if (!sample_geo<FEAT, true>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, a.sp.lb, a.sp.ub,
-                                          a.sc.vertex_normal, a.sc.albedo, g, t_self))
+                    if (GEO) {
+                        cached_geo<FEAT>(f, o, ch, cv, cw, a.sc.vertex_normal, a.sc.albedo, g);
+                    } else if (!sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, a.sp.lb, a.sp.ub,
+                                                 a.sc.vertex_normal, a.sc.albedo, g, t_self))
                         continue;   // cannot happen: pass 1 accepted this sample with the same arithmetic
                     const double twoh = (double)(2.0f * g.h);
                     if (MODE == 1 || MODE == 2) {
@@ -423,7 +442,7 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
                     } else {
                         Geo g;
                         float t_self;
-                        if (!sample_geo<FEAT, true>(f, tr, o, a.sp.seed, kbase + (uint64_t)((wi << 5) + bit), a.sp.lb, a.sp.ub,
+                        if (!sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)((wi << 5) + bit), a.sp.lb, a.sp.ub,
                                               a.sc.vertex_normal, a.sc.albedo, g, t_self))
                             continue;
                         grad_vectors<FEAT>(f, g, on, a.normal_term, a.v1_style, a.sp.ggx_alpha, gv);
@@ -521,6 +540,18 @@ bool gradient_fm_launch(const GradientArgs& a, hipStream_t stream) {
 template <int FEAT, int MODE>
 void gradient_launch2(const GradientArgs& a, int grid, size_t lds, hipStream_t stream, bool wide = false) {
     if constexpr (MODE == 0) {
+        if (a.geo && a.vis_items) {      // pass 1's geometry cache (and the item masks that index it)
+            if (wide) {
+                note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, 0, false, 1024, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(dynamic LDS)");
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, 0, false, 1024, true>), dim3(grid), dim3(1024), lds, stream, a);
+                return;
+            }
+            note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, 0, false, NLOS_GRAD_NT, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(dynamic LDS)");
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gradient<FEAT, 0, false, NLOS_GRAD_NT, true>), dim3(grid), dim3(NLOS_GRAD_NT), lds, stream, a);
+            return;
+        }
         if (wide) {
             note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gradient<FEAT, 0, false, 1024>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(dynamic LDS)");

@@ -104,6 +104,9 @@ struct nlos_ctx {
     DevBuf vis, diff, fine, taps, rows_tmp, grad_tmp, live;
     DevBuf reg_normal, reg_area, reg_owner;
     DevBuf vis2, tile_list, tile_count, cov;
+    DevBuf geo;                      // pass 1 -> pass 2 geometry cache (h, v, w per ray of the live lists)
+    int64_t geo_gen = 0;             // the visibility generation the geometry cache was recorded with (0: none)
+    int geo_stride = 0;
     DevBuf prod_rec, prod_pairs;     // the product of row N: per-wall-point records; enumerated pairs of the fallback
     int tap_refine = -1, tap_sigma = -1; float tap_res = -1.0f; int tap_kind = -1;
     // host-pointer path staging
@@ -373,7 +376,7 @@ void nlos_ctx_destroy(nlos_ctx* c) {
     DeviceGuard g(c->device);
     DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                      &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag, &c->vis_items, &c->prod_rec, &c->prod_pairs};
+                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag, &c->vis_items, &c->prod_rec, &c->prod_pairs, &c->geo};
     for (DevBuf* b : all) b->release();
     for (DevBuf& b : c->io) b.release();
     for (hipEvent_t& e : c->ring) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
@@ -386,7 +389,7 @@ int64_t nlos_ctx_scratch_bytes(const nlos_ctx* c) {
     if (!c) return 0;
     const DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                            &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag, &c->vis_items, &c->prod_rec, &c->prod_pairs};
+                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag, &c->vis_items, &c->prod_rec, &c->prod_pairs, &c->geo};
     int64_t s = 0;
     for (const DevBuf* b : all) s += (int64_t)b->cap;
     for (const DevBuf& b : c->io) s += (int64_t)b.cap;
@@ -569,6 +572,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.force_bvh = (a->force_bvh == 1 || v1_point) ? 1 : 0;
     fa.dbg = nullptr;
     fa.rec_d = fa.rec_ff = nullptr;
+    fa.geo = nullptr; fa.geo_stride = 0;
     fa.live = nullptr;
     fa.cov = nullptr;
     fa.tile_list = nullptr;
@@ -668,6 +672,14 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
             if (rc) return rc;
             fa.vis_items = c->vis_items.as<unsigned long long>();
             fa.items_stride = stride;
+            // geometry cache for the pass 2 of THIS call (vertex-gradient modes, confocal): 12 B per ray of the live lists
+            static const bool geo_enabled = [] { const char* e = std::getenv("NLOS_GEO_CACHE"); return !e || std::atoi(e) != 0; }();
+            if (geo_enabled && !a->sensor && !jitter && (mode == NLOS_MODE_GRADIENT || mode == NLOS_MODE_GRADIENT_V1 || mode == NLOS_MODE_TRANSIENT)) {
+                rc = c->geo.ensure(sizeof(float) * 3 * (size_t)L * (size_t)nF * (size_t)spt + 16);
+                if (rc) return rc;
+                fa.geo = c->geo.as<float>();
+                fa.geo_stride = nF * spt;
+            }
         }
         c->vis_key = key;
         if (!skip_pass1) c->vis_gen = ++c->gen_counter;
@@ -714,6 +726,10 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     c->path_retry_workgroups = note.retry_workgroups;
     if (note.tree_built) c->tree_complete = true;
     if (!skip_pass1 && fa.vis) { c->vis_is_items = note.vis_items != 0; c->vis_items_stride = fa.items_stride; }
+    if (!skip_pass1) {     // the geometry cache belongs to the visibility generation it was recorded with
+        c->geo_gen = (fa.geo && fa.vis && note.vis_items != 0) ? c->vis_gen : 0;
+        c->geo_stride = fa.geo_stride;
+    }
 #ifdef NLOS_FWD_STAMPS
     {
         long long h[26];
@@ -827,6 +843,10 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         ga.live = c->live.as<uint16_t>();
         ga.items_stride = c->vis_items_stride;
         ga.vis_scratch = c->vis.as<uint32_t>();
+        // the geometry cache recorded together with the visibility cache this pass 2 reads (by pass 1 of this call, or --
+        // reuse_visibility -- by the render that recorded that generation), as item masks (the cache's index)
+        ga.geo = (c->vis_is_items && c->geo_gen != 0 && c->geo_gen == c->vis_gen && c->geo.p) ? c->geo.as<float>() : nullptr;
+        ga.geo_stride = c->geo_stride;
         ga.tap_w = c->taps.as<double>(); ga.tap_delta = ga.tap_w + K; ga.tap_g = ga.tap_w + 2 * K;
         ga.tap_p0 = ga.tap_w + 3 * K; ga.tap_p1 = ga.tap_w + 4 * K + 1; ga.tap_pw = ga.tap_w + 5 * K + 2;
         ga.K = K;

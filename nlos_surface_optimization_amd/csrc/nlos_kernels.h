@@ -118,6 +118,11 @@ struct ForwardArgs {
     int* tile_count;         // [L * tiles] subset sizes (may exceed tile_cap: overflow), filled by k_tile_bin
     int tiles_x, tiles_y, tile_cap;
     int* retry;              // [workgroups] flags of the big-LDS second launch (grid kernels) or null
+    // Geometry cache pass 1 -> pass 2 (round 4; confocal single-workgroup grid with item masks only): per ray r = li * spt + s
+    // of the bucketed live list the three numbers pass 2 cannot get cheaply -- h and the hit's barycentrics (v, w) of
+    // sample_geo() -- so that pass 2 neither hashes, nor takes square roots, nor repeats the own-face triangle test.
+    float* geo;              // [L, geo_stride, 3] or null
+    int geo_stride;          // rays per source the cache holds (F * spt)
     // record pass of the product (row N as L x S): per wall point and sample r = sorted face slot * spt + s, the path
     // length of the leg and its clamped form factor, 0 where the sample is not seen from that wall point
     float* rec_d;            // [L, F * spt] or null
@@ -184,6 +189,8 @@ struct GradientArgs {
     const uint16_t* live;                  // [L, F] bucketed live lists the item masks refer to
     int items_stride;
     uint32_t* vis_scratch;                 // [L, vis_words, F]: where the face-major kernel gets per-face words from item masks
+    const float* geo;                      // geometry cache of pass 1 (ForwardArgs::geo; item-mask layout only) or null
+    int geo_stride;
     const double* tap_w;     // [K] weighting_kernal
     const double* tap_delta; // [K] delta_length (float-evaluated, widened)
     const double* tap_g;     // [K] (float)(delta/sigma^2*2) widened

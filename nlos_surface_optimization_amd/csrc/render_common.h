@@ -77,10 +77,7 @@ struct Geo {
 // Row S + the own-face part of row I: stratified sample -> ray -> hit on face j.
 // Returns false if the ray misses its own triangle (edge rounding) or the path
 // length is outside [lb/2, ub/2].
-// P2 (pass 2 only) with -DNLOS_DIAG_GRAD_FREE_H: diagnostic build that takes the hit's barycentrics and h as if pass 1 had
-// stored them (no own-face test, no second square root) -- the upper bound of what such a cache could save; results
-// differ in the last bits.
-template <int FEAT, bool P2 = false>
+template <int FEAT>
 __device__ __forceinline__ bool sample_geo(const Face& f, const Tri& tr, V3 o, uint64_t seed, uint64_t k,
                                            float lb, float ub, const float* __restrict__ vn,
                                            const float* __restrict__ alb, Geo& g, float& t_self) {
@@ -94,14 +91,6 @@ __device__ __forceinline__ bool sample_geo(const Face& f, const Tri& tr, V3 o, u
     V3 d = p - o;
     float rs = 1.0f / sqrtf(dot(d, d));
     g.dir = d * rs;
-#ifdef NLOS_DIAG_GRAD_FREE_H
-    if (P2) {
-        g.u = u; g.v = v; g.w = w;
-        g.h = __builtin_amdgcn_rcpf(rs);
-        t_self = g.h;
-    } else
-#endif
-    {
     float hu, hv;
     if (!tri_test(tr, o, g.dir, t_self, hu, hv)) return false;
     g.v = hu;
@@ -111,7 +100,6 @@ __device__ __forceinline__ bool sample_geo(const Face& f, const Tri& tr, V3 o, u
     V3 dq = q - o;
     g.h = sqrtf(dot(dq, dq));
     if (!((g.h <= ub / 2.0f) && (g.h >= lb / 2.0f))) return false;
-    }
     g.n = f.fn;
     if (FEAT & FEAT_VN) {
         g.n = bary(g.u, ld3(vn + 3 * (size_t)f.i0), g.v, ld3(vn + 3 * (size_t)f.i1), g.w,
@@ -120,6 +108,27 @@ __device__ __forceinline__ bool sample_geo(const Face& f, const Tri& tr, V3 o, u
     g.alb = 1.0f;
     if (FEAT & FEAT_ALB) g.alb = g.u * alb[f.i0] + g.v * alb[f.i1] + g.w * alb[f.i2];
     return true;
+}
+
+// The same Geo from pass 1's geometry cache (h and the hit's barycentrics v, w, bit for bit what sample_geo() computed):
+// the hit point is rebuilt from them, the direction is the unit vector towards it -- sample_geo()'s direction towards the
+// SAMPLED point up to the rounding of the hit's barycentrics (1e-7; pass 2 decides nothing, its bins come from h).
+template <int FEAT>
+__device__ __forceinline__ void cached_geo(const Face& f, V3 o, float h, float hv, float hw, const float* __restrict__ vn,
+                                           const float* __restrict__ alb, Geo& g) {
+    g.v = hv;
+    g.w = hw;
+    g.u = 1.0f - g.v - g.w;
+    const V3 q = bary(g.u, f.p0, g.v, f.p1, g.w, f.p2);
+    g.h = h;
+    g.dir = (q - o) * __builtin_amdgcn_rcpf(h);
+    g.n = f.fn;
+    if (FEAT & FEAT_VN) {
+        g.n = bary(g.u, ld3(vn + 3 * (size_t)f.i0), g.v, ld3(vn + 3 * (size_t)f.i1), g.w,
+                   ld3(vn + 3 * (size_t)f.i2));
+    }
+    g.alb = 1.0f;
+    if (FEAT & FEAT_ALB) g.alb = g.u * alb[f.i0] + g.v * alb[f.i1] + g.w * alb[f.i2];
 }
 
 __device__ __forceinline__ float emax0(float x) { return 0.0f < x ? x : 0.0f; }
