@@ -188,8 +188,8 @@ def workload_config(args, g, T, F, V, spt, L_total, world):
                         g, g, "" if world == 1 else (" split over %d ranks" % world if args.scaling == "strong" else " per rank"),
                         T, args.mesh, F, V, args.num_sample, spt),
         "sources_total": L_total, "faces": F, "bins": T, "spt": spt,
-        "parallelism": "source sharding x%d (%s) + one all-reduce of the 3V gradient" % (
-            world, "one grid per rank" if args.scaling == "weak" else args.partition + " partition"),
+        "parallelism": "source sharding x%d (%s) + one all-reduce of the 3V gradient (%s)" % (
+            world, "one grid per rank" if args.scaling == "weak" else args.partition + " partition", args.all_reduce),
     }
 
 
@@ -227,6 +227,9 @@ def parse_args(argv=None):
                     help="strong scaling: which sources a rank owns -- a contiguous block of the grid (the reference's own "
                          "batching, exp_bunny/test.py:66-67) or every N-th source (l = rank mod N: an even sample of the wall, "
                          "so the ranks finish together; default).  Results do not depend on it (RNG keys are global).")
+    ap.add_argument("--all-reduce", choices=["torch", "rccl-direct"], default="torch",
+                    help="N > 1: the gradient all-reduce through torch.distributed (default), or enqueued on the render stream by a "
+                         "communicator of the process's own (dist.RcclDirect; exercised at world size 1 only so far)")
     ap.add_argument("--share-steps", type=int, default=10,
                     help="N = 1, metric workload: after the timed steps, time every rank's block of the 2-, 4- and 8-way strong "
                          "split for this many steps each and report them as `strong_share` (0 = skip)")
@@ -416,6 +419,10 @@ def run_rank(args, backend):
             dist.destroy_process_group()
         return 1
 
+    direct = None
+    if world > 1 and args.all_reduce == "rccl-direct":
+        direct = ndist.RcclDirect(rank, world, dev)
+
     def step():
         if args.forward_only:
             r.render_transient(origin, normal, verts, faces, args.num_sample, lb, ub, res,
@@ -424,7 +431,9 @@ def run_rank(args, backend):
             r.render_gradient(origin, normal, verts, faces, args.num_sample, lb, ub, res, data=data,
                               weight=weight, refine_scale=10, sigma_bin=1, testing_flag=1, loss_flag=0,
                               gradient=grad, zero_gradient=True, total_sources=L_total, **keys, **nc)
-            if world > 1:
+            if direct is not None:
+                direct.all_reduce_sum_(grad)
+            elif world > 1:
                 dist.all_reduce(grad, op=dist.ReduceOp.SUM)
 
     def timed(n_steps):

@@ -10,8 +10,15 @@ bound).  Each rank scales by 1/L_global inside the kernel
 (smoothed_transient/transient_and_gradient.cpp:563), so the reduced gradient equals the
 single-GPU one up to fp64 summation order.
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
+
+
+class _NcclUniqueId(ctypes.Structure):          # ncclUniqueId: 128 opaque bytes, passed by value
+    _fields_ = [("internal", ctypes.c_char * 128)]
 
 
 def shard_bounds(n_sources, rank, world_size):
@@ -40,6 +47,64 @@ def shard_slice(n_sources, rank, world_size, partition="contiguous"):
     return slice(int(rank), int(n_sources), int(world_size)), int(rank), int(world_size)
 
 
+class RcclDirect:
+    """The vertex-gradient all-reduce enqueued by this process itself on the stream the render kernels run on.
+
+    torch.distributed's "nccl" backend (= RCCL) runs every collective on a stream of its own and hands over with two
+    events (current stream -> collective stream -> current stream); on a 0.33 ms step of an 8-way split that hand-off is a
+    visible share of the 58 KB all-reduce.  This class opens a communicator of its OWN on the librccl.so torch ships
+    (ctypes: ncclGetUniqueId on rank 0, the 128-byte id broadcast through the existing torch process group,
+    ncclCommInitRank) and calls ncclAllReduce(sum, float64, in place) directly on `torch.cuda.current_stream()`.
+    STATUS: exercised with world size 1 on the GPU (tests/test_gpu_dist.py) -- no multi-GPU node has been available to
+    this build, so like every N > 1 path here it is unmeasured on hardware; ShardedRenderer uses it only on request
+    (all_reduce="rccl-direct")."""
+
+    NCCL_FLOAT64, NCCL_SUM = 8, 0
+
+    def __init__(self, rank, world_size, device, group=None, lib_path=None):
+        if lib_path is None:
+            lib_path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self._lib = ctypes.CDLL(lib_path)
+        self._lib.ncclGetErrorString.restype = ctypes.c_char_p
+        self._lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
+        self._lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_void_p, ctypes.c_void_p]
+        self.device = torch.device(device)
+        uid = _NcclUniqueId()
+        if rank == 0:
+            self._check(self._lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        if world_size > 1:
+            # the id travels through the process group that already exists (device tensor for "nccl", host for "gloo")
+            on_gpu = dist.get_backend(group) == "nccl"
+            buf = torch.frombuffer(bytearray(bytes(uid.internal) if rank == 0 else bytes(128)), dtype=torch.uint8).clone()
+            if on_gpu:
+                buf = buf.to(self.device)
+            dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ctypes.memmove(ctypes.byref(uid), bytes(buf.cpu().numpy().tobytes()), 128)
+        self._comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            self._check(self._lib.ncclCommInitRank(ctypes.byref(self._comm), int(world_size), uid, int(rank)), "ncclCommInitRank")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, self._lib.ncclGetErrorString(rc).decode()))
+
+    def all_reduce_sum_(self, tensor):
+        """In-place float64 sum over the ranks, enqueued on the current stream of the tensor's device."""
+        assert tensor.is_cuda and tensor.dtype == torch.float64 and tensor.is_contiguous()
+        stream = torch.cuda.current_stream(tensor.device).cuda_stream
+        p = ctypes.c_void_p(tensor.data_ptr())
+        with torch.cuda.device(tensor.device):
+            self._check(self._lib.ncclAllReduce(p, p, tensor.numel(), self.NCCL_FLOAT64, self.NCCL_SUM, self._comm,
+                                                ctypes.c_void_p(stream)), "ncclAllReduce")
+        return tensor
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self._lib.ncclCommDestroy(self._comm)
+            self._comm = None
+
+
 def all_reduce_gradient(gradient, group=None):
     """Sum the per-rank partial vertex gradients in place (no-op without a process group)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -55,7 +120,7 @@ class ShardedRenderer:
     the sharding and collective logic under gloo).  `partition`: see shard_slice().
     """
 
-    def __init__(self, renderer, n_sources, rank=None, world_size=None, group=None, partition="contiguous"):
+    def __init__(self, renderer, n_sources, rank=None, world_size=None, group=None, partition="contiguous", all_reduce="torch"):
         if rank is None:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
         if world_size is None:
@@ -64,6 +129,10 @@ class ShardedRenderer:
         self.n_sources = int(n_sources)
         self.rank, self.world_size, self.group = rank, world_size, group
         self.partition = partition
+        if all_reduce not in ("torch", "rccl-direct"):
+            raise ValueError("all_reduce must be 'torch' or 'rccl-direct'")
+        # "rccl-direct": a communicator of this process's own, collectives on the render stream (see RcclDirect)
+        self.direct = RcclDirect(rank, world_size, renderer.device, group) if all_reduce == "rccl-direct" else None
         self.slice, self.offset, self.stride = shard_slice(n_sources, rank, world_size, partition)
         self.lo, self.hi = shard_bounds(n_sources, rank, world_size)   # (contiguous partition; kept for callers that index by block)
 
@@ -89,7 +158,10 @@ class ShardedRenderer:
         regulariser gradient present on every rank) is not multiplied by the world size."""
         into = kw.pop("gradient", None)
         transient, gradient, path = self.renderer.render_gradient(origin, normal, *args, **self._keys(), **kw)
-        all_reduce_gradient(gradient, self.group)
+        if self.direct is not None:
+            self.direct.all_reduce_sum_(gradient)
+        else:
+            all_reduce_gradient(gradient, self.group)
         if into is not None:
             into += gradient
             gradient = into

@@ -88,5 +88,20 @@ def test_rccl_group_and_sharded_blocks(bunny):
                 assert rel_l2(t.cpu().numpy(), t_o) < 1e-12 and rel_l2(g.cpu().numpy(), g_o) < 1e-4
         assert rel_l2(full.cpu().numpy(), t_ref.cpu().numpy()) < 1e-12
         assert rel_l2(acc.cpu().numpy(), g_ref.cpu().numpy()) < 1e-6
+
+        # "rccl-direct": a communicator of the process's own on torch's librccl.so, ncclAllReduce enqueued on the render
+        # stream itself (world size 1 here: the sum over one rank, in stream order behind the kernels that produce it)
+        sd = ShardedRenderer(r, L, all_reduce="rccl-direct")
+        try:
+            t5, g5, _ = sd.render_gradient(origin, normal, v, f, ns, LB, UB, RES, data=data, weight=weight)
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):            # ... and on whatever stream is current
+                t6, g6, _ = sd.render_gradient(origin, normal, v, f, ns, LB, UB, RES, data=data, weight=weight)
+            side.synchronize()
+            torch.cuda.synchronize()
+            assert rel_l2(g5.cpu().numpy(), g_ref.cpu().numpy()) < 1e-6 and rel_l2(g6.cpu().numpy(), g_ref.cpu().numpy()) < 1e-6
+            assert rel_l2(t5.cpu().numpy(), t_ref.cpu().numpy()) < 1e-12
+        finally:
+            sd.direct.close()
     finally:
         dist.destroy_process_group()

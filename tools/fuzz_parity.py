@@ -176,6 +176,29 @@ def main():
                 t, _ = r.render_transient(to, tn, tv, tf_, ns, lb, ub, res, sensor=tb, sensor_normal=tn, force_bvh=fb)
                 en = max(en, rel_l2(t.cpu().numpy(), tn_ref))
             et = max(et, en)
+        ep = 0.0
+        if rs.rand() < 0.3:
+            # row N as a product (round 4): a few lasers x a few sensors on shared samples -- the record + combine kernels
+            # where the scene allows them, the enumerated pairs otherwise -- against the pair oracle on the enumerated pairs
+            La, Sb = int(rs.randint(1, 5)), int(rs.randint(1, 5))
+            pl = np.ascontiguousarray(o[rs.randint(0, L, La)])
+            ps = np.zeros((Sb, 3), np.float32)
+            ps[:, :2] = rs.uniform(-0.6, 0.6, (Sb, 2))
+            if rs.rand() < 0.3:
+                ps[0] = pl[0]                              # a wall point that is laser and sensor
+            pn, sn = np.tile(np.array([0, 0, 1], np.float32), (La, 1)), np.tile(np.array([0, 0, 1], np.float32), (Sb, 1))
+            lbp = float(np.float32(max(0.0, lb - 0.1)))
+            ubp = float(np.float32(np.float32(lbp) + np.float32(T) * np.float32(res)))
+            tp_ref, _, _ = orc.render_product(pl, pn, ps, sn, v, f, ns, lbp, ubp, res, accel=1, seed=case)
+            tpl, tpn, tps, tsn = (torch.from_numpy(x).to(dev) for x in (pl, pn, ps, sn))
+            tp, _, _ = r.render_product(tpl, tpn, tps, tsn, tv, tf_, ns, lbp, ubp, res)
+            ep = rel_l2(tp.cpu().numpy(), tp_ref)
+            if tp_ref.sum() > 0 and rs.rand() < 0.5:
+                dp = tp_ref * (1 + 0.3 * rs.standard_normal(tp_ref.shape))
+                _, gp_ref, _ = orc.render_product(pl, pn, ps, sn, v, f, ns, lbp, ubp, res, data=dp, accel=1, seed=case)
+                _, gp, _ = r.render_product(tpl, tpn, tps, tsn, tv, tf_, ns, lbp, ubp, res, data=torch.from_numpy(dp).to(dev))
+                eg = max(eg, rel_l2(gp.cpu().numpy(), gp_ref))
+            et = max(et, ep)
         ex = 0.0
         if rs.rand() < 0.3 and F <= 6200:
             # other rows on the same scene: GGX branch, SPAD jitter gradient, v1 driver, per-face intensity
@@ -207,8 +230,8 @@ def main():
         differing += int(et > 1e-12)
         bad += int(not ok)
         worst_t, worst_g = max(worst_t, et), max(worst_g, eg)
-        print("case %3d F=%6d L=%4d spt=%2d T=%4d vn=%d sum=%.3e  transient %.2e (grid/bvh%s, oracle bvh vs all-faces %.1e)  gradient %.2e  nc %.2e  ggx/jitter/intensity %.2e %s" % (
-            case, F, L, spt, T, int(use_vn), t_ref.sum(), et, "/ovf" if F > 6200 else "", e_def, eg, en, ex, "" if ok else "  <-- MISMATCH"),
+        print("case %3d F=%6d L=%4d spt=%2d T=%4d vn=%d sum=%.3e  transient %.2e (grid/bvh%s, oracle bvh vs all-faces %.1e)  gradient %.2e  nc %.2e  product %.2e  ggx/jitter/intensity %.2e %s" % (
+            case, F, L, spt, T, int(use_vn), t_ref.sum(), et, "/ovf" if F > 6200 else "", e_def, eg, en, ep, ex, "" if ok else "  <-- MISMATCH"),
             flush=True)
     print("empty draws (resampled, GPU rows checked to be zero): %d, of which non-zero on the GPU: %d" % (empties, empties_bad))
     print("cases with a differing sample (see tools/fuzz_case.py): %d" % (differing + empties_bad))
