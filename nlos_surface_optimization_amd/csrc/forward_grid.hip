@@ -1259,6 +1259,13 @@ __global__ __launch_bounds__(kGridNT, kGridNT / 128) void k_forward_grid(Forward
     __shared__ uint32_t s_bkt[32];                   // live faces per list-length bucket, then the write cursors
     const int pass = PASS >= 0 ? PASS : pass_arg;
     if (pass >= 1 && a.retry[blockIdx.x] != pass) return;  // second launch: only the workgroups flagged for it
+    if (!TILED && NCM == 0 && pass == 0) {
+        // the chores of the residual launch (ForwardArgs::zero / pathlengths): done here when pass 2 forms the residual itself
+        if (a.zero)
+            for (size_t i = (size_t)blockIdx.x * kGridNT + threadIdx.x; i < a.zero_n; i += (size_t)gridDim.x * kGridNT) a.zero[i] = 0.0;
+        if (a.pathlengths && blockIdx.x == 0)
+            for (int i = threadIdx.x; i < a.path_T; i += kGridNT) a.pathlengths[i] = (double)(a.path_lb + i * a.path_res);
+    }
     if (grid_body<FEAT, NCM, TILED, false>(a, rows_in_lds, R, cap, pass, last_pass, s_scan, s_bkt)) {
         __syncthreads();
         grid_body<FEAT, NCM, TILED, true>(a, rows_in_lds, R, cap, pass, last_pass, s_scan, s_bkt);
@@ -1329,6 +1336,7 @@ bool forward_grid_launch(const ForwardArgs& a_in, int rows_in_lds, hipStream_t s
     note.backend = 1; note.reason = 0; note.grid_R = R; note.tiles = 1; note.tile_cap = 0;
     note.retry_workgroups = a.retry ? a.src.L : 0;
     if (items) note.vis_items = 1;
+    if (NCM == 0) note.prologue_done = 1;      // (ForwardArgs::zero / pathlengths, if any, are handled by the kernel's first workgroups)
     // kScan slots of slack: the walk reads kScan entries per trip and may touch the slots after the last list
     const int last_pass = a.retry ? 1 : 0;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_forward_grid<FEAT, NCM, false, 0>), dim3(a.src.L), dim3(kGridNT), lds, stream, a, rows_in_lds, R,

@@ -9,6 +9,7 @@
 #include "render_common.h"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace nlos {
 namespace {
@@ -85,7 +86,15 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
         __syncthreads();                    // previous source done with s_diff
         // vertex-gradient modes read the row only as (float)(-2 d): rounded once here instead of once per tap group
         for (int i = threadIdx.x; i < T; i += blockDim.x) {
-            const double d = a.diff[(size_t)l * T + i];
+            double d;
+            if (a.inline_residual) {
+                // row D here instead of in a launch of its own: difference = (data - transient) [-> 2 d^3] * weight
+                d = a.res_data[(size_t)l * T + i] - a.res_transient[(size_t)l * T + i];
+                if (a.res_loss_test == 1) d = 2 * d * d * d;
+                if (a.res_weight) d = d * a.res_weight[(size_t)l * T + i];
+            } else {
+                d = a.diff[(size_t)l * T + i];
+            }
             s_diff[i] = (MODE == 0 || MODE == 4) ? (double)(float)((-2) * d) : (-2) * d;      // scalar modes: -2 d in double
         }
         if (threadIdx.x == 0) *s_next = 0;
@@ -610,6 +619,15 @@ void launch_gradient(const GradientArgs& a_in, hipStream_t stream) {
     // per-workgroup 3V-double accumulator while it fits beside the rest (one workgroup per CU at worst)
     const size_t acc = 3 * (size_t)a.sc.V * sizeof(double);
     a.lds_grad = ((a.mode == 0 || a.mode == 4) && a_in.lds_grad && lds + acc <= 150 * 1024) ? 1 : 0;
+    if (a.inline_residual && !a.lds_grad && (a.mode == 0 || a.mode == 4) && a_in.lds_grad) {
+        // the face-major kernel reads residual rows: form them first
+        ResidualArgs ra;
+        std::memset(&ra, 0, sizeof(ra));
+        ra.data = a.res_data; ra.weight = a.res_weight; ra.transient = a.res_transient; ra.diff = a.diff_scratch;
+        ra.L = a.src.L; ra.T = a.sp.nbins; ra.loss_test = a.res_loss_test;
+        launch_residual(ra, stream);
+        a.diff = a.diff_scratch; a.inline_residual = 0;
+    }
     if (!a.lds_grad && (a.mode == 0 || a.mode == 4) && a_in.lds_grad) {
         // large meshes: face-major variant (per-face sums in LDS across sources, one scatter per face)
         if (a.vis_items && a.vis_scratch) {

@@ -573,6 +573,16 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.dbg = nullptr;
     fa.rec_d = fa.rec_ff = nullptr;
     fa.geo = nullptr; fa.geo_stride = 0;
+    // Residual formed by pass 2 itself (round 4): vertex gradient of this call's own forward rows, confocal; k_residual's
+    // other chores (clearing the gradient output, the pathlengths) then ride in the grid kernel's first workgroups, and the
+    // step holds no residual launch.  Whether the launcher that runs carries them is known after the launch (note.prologue_done).
+    static const bool fuse_enabled = [] { const char* e = std::getenv("NLOS_FUSE_RESIDUAL"); return !e || std::atoi(e) != 0; }();
+    const bool fuse_candidate = fuse_enabled && mode == NLOS_MODE_GRADIENT && !a->residual && !a->sensor && !a->reuse_visibility;
+    fa.zero = nullptr; fa.zero_n = 0; fa.pathlengths = nullptr; fa.path_lb = lb; fa.path_res = res; fa.path_T = T;
+    if (fuse_candidate) {
+        if (a->zero_gradient) { fa.zero = a->gradient; fa.zero_n = 3 * (size_t)nV; }
+        fa.pathlengths = a->pathlengths;
+    }
     fa.live = nullptr;
     fa.cov = nullptr;
     fa.tile_list = nullptr;
@@ -811,7 +821,14 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         nlos::launch_residual(ra, st);
         zero_ptr = nullptr;
     }
-    if (needs_grad && !a->residual) {
+    const bool fused_residual = fuse_candidate && note.prologue_done != 0;
+    if (fused_residual) {
+        rc = c->diff.ensure(sizeof(double) * (size_t)L * T + 16);      // (scratch of the face-major fallback only)
+        if (rc) return rc;
+        diff_ptr = c->diff.as<double>();
+        zero_ptr = nullptr;                                            // cleared by the grid kernel's first workgroups
+    }
+    if (needs_grad && !a->residual && !fused_residual) {
         rc = c->diff.ensure(sizeof(double) * (size_t)L * T + 16);
         if (rc) return rc;
         nlos::ResidualArgs ra;
@@ -847,6 +864,9 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         // reuse_visibility -- by the render that recorded that generation), as item masks (the cache's index)
         ga.geo = (c->vis_is_items && c->geo_gen != 0 && c->geo_gen == c->vis_gen && c->geo.p) ? c->geo.as<float>() : nullptr;
         ga.geo_stride = c->geo_stride;
+        ga.inline_residual = fused_residual ? 1 : 0;
+        ga.res_data = a->data; ga.res_weight = a->weight; ga.res_transient = transient; ga.res_loss_test = a->loss_test;
+        ga.diff_scratch = c->diff.as<double>();
         ga.tap_w = c->taps.as<double>(); ga.tap_delta = ga.tap_w + K; ga.tap_g = ga.tap_w + 2 * K;
         ga.tap_p0 = ga.tap_w + 3 * K; ga.tap_p1 = ga.tap_w + 4 * K + 1; ga.tap_pw = ga.tap_w + 5 * K + 2;
         ga.K = K;

@@ -11,6 +11,7 @@ namespace nlos {
 struct LaunchNote {
     int backend = 0, reason = 0, grid_R = 0, tiles = 0, tile_cap = 0, rows_in_lds = 0, gradient_kernel = 0;
     int retry_workgroups = 0;        // entries of the retry / path-code array the grid launches wrote
+    int prologue_done = 0;           // 1: the pass-1 kernel cleared ForwardArgs::zero and wrote ForwardArgs::pathlengths itself
     int vis_items = 0;               // 1: pass 1 recorded the visibility cache as item masks (ForwardArgs::vis_items), not per-face words
     // lazy scene build (grid back-end): the records exist, the tree does not yet.  The launchers complete it -- on a
     // device-side flag between the grid's two launches, unconditionally in front of a BVH back-end
@@ -118,6 +119,13 @@ struct ForwardArgs {
     int* tile_count;         // [L * tiles] subset sizes (may exceed tile_cap: overflow), filled by k_tile_bin
     int tiles_x, tiles_y, tile_cap;
     int* retry;              // [workgroups] flags of the big-LDS second launch (grid kernels) or null
+    // What k_residual does besides the residual, carried by the first workgroups of the single-workgroup grid kernel when
+    // pass 2 computes the residual itself (GradientArgs::inline_residual): the step then holds no residual launch.
+    double* zero;            // [zero_n] cleared (the gradient output of zero_gradient renders) or null
+    size_t zero_n;
+    double* pathlengths;     // [path_T] = (double)(path_lb + i * path_res) or null
+    float path_lb, path_res;
+    int path_T;
     // Geometry cache pass 1 -> pass 2 (round 4; confocal single-workgroup grid with item masks only): per ray r = li * spt + s
     // of the bucketed live list the three numbers pass 2 cannot get cheaply -- h and the hit's barycentrics (v, w) of
     // sample_geo() -- so that pass 2 neither hashes, nor takes square roots, nor repeats the own-face triangle test.
@@ -191,6 +199,15 @@ struct GradientArgs {
     uint32_t* vis_scratch;                 // [L, vis_words, F]: where the face-major kernel gets per-face words from item masks
     const float* geo;                      // geometry cache of pass 1 (ForwardArgs::geo; item-mask layout only) or null
     int geo_stride;
+    // inline_residual = 1: `diff` is scratch, the kernel forms (data - transient)[^3 * 2] * weight itself while it stages a
+    // source's row in LDS (row D, smoothed_transient/stratifiedStreamedGradientRenderer.cpp:543-550); the face-major kernel
+    // does not, the launcher then runs k_residual into `diff_scratch` first
+    int inline_residual;
+    const double* res_data;                // [L,T]
+    const double* res_weight;              // [L,T] or null
+    const double* res_transient;           // [L,T]
+    int res_loss_test;
+    double* diff_scratch;                  // [L,T]
     const double* tap_w;     // [K] weighting_kernal
     const double* tap_delta; // [K] delta_length (float-evaluated, widened)
     const double* tap_g;     // [K] (float)(delta/sigma^2*2) widened
