@@ -951,7 +951,10 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                         // the item mask -- three more registers live across the trace -- it costs more: 1.399 ms;
                         // profiles/r04_ab_geo_cache.log.)
                         float* gp = geo_l + 3 * (size_t)r;
-                        gp[0] = gg.h; gp[1] = gg.v; gp[2] = gg.w;
+                        // streaming (non-temporal) stores, and non-temporal loads in pass 2: written once, read once, 590 MB per
+                        // launch -- kept out of the way of the scene records the L2 serves all the time.  Together: forward
+                        // 1.370 -> 1.350 ms, pass 2 0.457 -> 0.468 ms; either alone is a loss (profiles/r04_ab_geo_nt.log).
+                        __builtin_nontemporal_store(gg.h, gp); __builtin_nontemporal_store(gg.v, gp + 1); __builtin_nontemporal_store(gg.w, gp + 2);
                     }
                 }
             } else if (NCM == 3) {

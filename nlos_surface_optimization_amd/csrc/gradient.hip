@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                 float nh = 0.0f, nv = 0.0f, nw = 0.0f;
                 if (GEO && word) {
                     const float* gp = geo_l + 3 * ((size_t)e * (size_t)spt + (size_t)(__ffs(word) - 1));
-                    nh = gp[0]; nv = gp[1]; nw = gp[2];
+                    nh = __builtin_nontemporal_load(gp); nv = __builtin_nontemporal_load(gp + 1); nw = __builtin_nontemporal_load(gp + 2);
                 }
                 while (word) {
                     const int bit = __ffs(word) - 1;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                     const float ch = nh, cv = nv, cw = nw;
                     if (GEO && word) {
                         const float* gp = geo_l + 3 * ((size_t)e * (size_t)spt + (size_t)(__ffs(word) - 1));
-                        nh = gp[0]; nv = gp[1]; nw = gp[2];
+                        nh = __builtin_nontemporal_load(gp); nv = __builtin_nontemporal_load(gp + 1); nw = __builtin_nontemporal_load(gp + 2);
                     }
                     if (NC) {
                         // row N: two legs, d(d1 + d2)/dp = dirA + dirB; P1 carries the confocal factor 2
