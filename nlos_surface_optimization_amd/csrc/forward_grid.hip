@@ -376,7 +376,8 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     uint32_t* const visout = NCM == 1 ? a.vis2 : a.vis;
     // item-mask layout of the visibility cache (launcher: single-workgroup grid, confocal; then a.vis == nullptr)
     // geometry cache for pass 2 (confocal renders that record item masks: its index is the item masks' ray index)
-    float* const geo_l = (!TILED && NCM == 0 && a.geo && a.vis_items) ? a.geo + 3 * (size_t)l * (size_t)a.geo_stride : nullptr;
+    float* const geo_l = (!TILED && NCM == 0 && a.geo && a.vis_items) ? a.geo + 4 * (size_t)l * (size_t)a.geo_stride : nullptr;
+    float* const geo_w = geo_l ? a.geo + 4 * (size_t)a.geo_sources * (size_t)a.geo_stride + (size_t)l * (size_t)a.geo_stride : nullptr;
     // (the laser pass of non-confocal pairs records the pair's accepted samples the same way, round 4)
     unsigned long long* const vitems = (!TILED && (NCM == 0 || NCM == 2) && a.vis_items) ? a.vis_items + (size_t)l * (size_t)a.items_stride : nullptr;
 #ifdef NLOS_FWD_STAMPS
@@ -945,16 +946,23 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     bin = (int)floorf((2.0f * gg.h - lb) / res);
                     dir = gg.dir;
                     if (geo_l && ok) {
-                        // what pass 2 needs of this sample, written HERE (before the trace: the three values are dead
-                        // afterwards; an occluded ray's entry is simply never read).  One global_store_dwordx3 per item:
-                        // forward 1.341 -> 1.374 ms, pass 2 0.540 -> 0.447 ms.  (Deferred behind the next item's loads like
-                        // the item mask -- three more registers live across the trace -- it costs more: 1.399 ms;
-                        // profiles/r04_ab_geo_cache.log.)
-                        float* gp = geo_l + 3 * (size_t)r;
-                        // streaming (non-temporal) stores, and non-temporal loads in pass 2: written once, read once, 590 MB per
-                        // launch -- kept out of the way of the scene records the L2 serves all the time.  Together: forward
-                        // 1.370 -> 1.350 ms, pass 2 0.457 -> 0.468 ms; either alone is a loss (profiles/r04_ab_geo_nt.log).
-                        __builtin_nontemporal_store(gg.h, gp); __builtin_nontemporal_store(gg.v, gp + 1); __builtin_nontemporal_store(gg.w, gp + 2);
+                        // What pass 2 needs of this sample: the sampled direction and the hit's barycentrics (20 B: float4 + float),
+                        // written HERE, before the trace (the barycentrics are dead afterwards; an occluded ray's entry is never
+                        // read).  Record of (live-list entry li, stratum s) at [s][li]: pass 2 -- one lane per entry, one stratum
+                        // per trip -- reads 64 consecutive records per load and every cache line once.  Streaming stores here and
+                        // streaming loads there: ~1 GB written once and read once per launch stays out of the way of the scene
+                        // records the L2 serves all the time.  Measured (profiles/r04_ab_geo_cache.log, _nt.log, _layout.log):
+                        // forward 1.341 -> 1.366 ms, pass 2 0.548 -> 0.474 ms.  What was tried on the way: a 12-byte record (h, v, w,
+                        // direction rebuilt from the hit point) is faster (0.447 ms) but moves the gradient by up to 7e-5 on grazing
+                        // rays; records at [li][s] are fetched spt times by the streaming loads (0.60 ms); cached loads or stores
+                        // cost 2-3 % of the step; the store deferred behind the next item's loads costs three registers across
+                        // the trace (+0.03 ms).
+                        typedef float f4_t __attribute__((ext_vector_type(4)));
+                        const size_t at = (size_t)s * (size_t)F + (size_t)li;
+                        f4_t* gp = reinterpret_cast<f4_t*>(geo_l) + at;
+                        const f4_t rec = {gg.dir.x, gg.dir.y, gg.dir.z, gg.v};
+                        __builtin_nontemporal_store(rec, gp);
+                        __builtin_nontemporal_store(gg.w, geo_w + at);
                     }
                 }
             } else if (NCM == 3) {

@@ -103,7 +103,9 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
         const unsigned long long* it_l = a.vis_items ? a.vis_items + (size_t)l * (size_t)a.items_stride : nullptr;
         const uint16_t* live_l = a.vis_items ? a.live + (size_t)l * F : nullptr;
         // pass 1's geometry cache (vertex-gradient modes of confocal renders): h and the hit's barycentrics per ray of the live list
-        const float* geo_l = GEO ? a.geo + 3 * (size_t)l * (size_t)a.geo_stride : nullptr;
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        const f4_t* geo_l = GEO ? reinterpret_cast<const f4_t*>(a.geo) + (size_t)l * (size_t)a.geo_stride : nullptr;
+        const float* geo_w = GEO ? a.geo + 4 * (size_t)a.geo_sources * (size_t)a.geo_stride + (size_t)l * (size_t)a.geo_stride : nullptr;
         const int n_src = it_l ? (int)it_l[0] : F;
         // faces with at least one accepted sample, compacted in order (pass 1 left the masks)
         for (int b = wave; b < nblocks; b += nwaves) {
@@ -177,21 +179,25 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
 
             for (int wi = 0; wi < n_words; ++wi) {
                 uint32_t word = it_l ? ibits : visp[(size_t)wi * F];
-                // GEO: the record of the NEXT accepted sample is requested one sample ahead (a dependent 12-byte load per
+                // GEO: the record of the NEXT accepted sample is requested one sample ahead (a dependent load per
                 // sample in front of its arithmetic left the kernel waiting: 0.558 -> 0.503 ms only, profiles/r04_ab_geo_cache.log)
-                float nh = 0.0f, nv = 0.0f, nw = 0.0f;
+                f4_t nrec = {0.0f, 0.0f, 0.0f, 0.0f};
+                float nw = 0.0f;
                 if (GEO && word) {
-                    const float* gp = geo_l + 3 * ((size_t)e * (size_t)spt + (size_t)(__ffs(word) - 1));
-                    nh = __builtin_nontemporal_load(gp); nv = __builtin_nontemporal_load(gp + 1); nw = __builtin_nontemporal_load(gp + 2);
+                    const size_t at = (size_t)(__ffs(word) - 1) * (size_t)F + (size_t)e;      // [stratum][live-list entry]
+                    nrec = __builtin_nontemporal_load(geo_l + at);
+                    nw = __builtin_nontemporal_load(geo_w + at);
                 }
                 while (word) {
                     const int bit = __ffs(word) - 1;
                     word &= word - 1;
                     const int s = (wi << 5) + bit;
-                    const float ch = nh, cv = nv, cw = nw;
+                    const V3 cdir = mk(nrec.x, nrec.y, nrec.z);
+                    const float cv = nrec.w, cw = nw;
                     if (GEO && word) {
-                        const float* gp = geo_l + 3 * ((size_t)e * (size_t)spt + (size_t)(__ffs(word) - 1));
-                        nh = __builtin_nontemporal_load(gp); nv = __builtin_nontemporal_load(gp + 1); nw = __builtin_nontemporal_load(gp + 2);
+                        const size_t at = (size_t)(__ffs(word) - 1) * (size_t)F + (size_t)e;      // [stratum][live-list entry]
+                        nrec = __builtin_nontemporal_load(geo_l + at);
+                        nw = __builtin_nontemporal_load(geo_w + at);
                     }
                     if (NC) {
                         // row N: two legs, d(d1 + d2)/dp = dirA + dirB; P1 carries the confocal factor 2
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                     Geo g;
                     float t_self;
                     if (GEO) {
-                        cached_geo<FEAT>(f, o, ch, cv, cw, a.sc.vertex_normal, a.sc.albedo, g);
+                        cached_geo<FEAT>(f, o, cdir, cv, cw, a.sc.vertex_normal, a.sc.albedo, g);
                     } else if (!sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, a.sp.lb, a.sp.ub,
                                                  a.sc.vertex_normal, a.sc.albedo, g, t_self))
                         continue;   // cannot happen: pass 1 accepted this sample with the same arithmetic

@@ -106,7 +106,7 @@ struct nlos_ctx {
     DevBuf vis2, tile_list, tile_count, cov;
     DevBuf geo;                      // pass 1 -> pass 2 geometry cache (h, v, w per ray of the live lists)
     int64_t geo_gen = 0;             // the visibility generation the geometry cache was recorded with (0: none)
-    int geo_stride = 0;
+    int geo_stride = 0, geo_sources = 0;
     DevBuf prod_rec, prod_pairs;     // the product of row N: per-wall-point records; enumerated pairs of the fallback
     int tap_refine = -1, tap_sigma = -1; float tap_res = -1.0f; int tap_kind = -1;
     // host-pointer path staging
@@ -572,7 +572,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.force_bvh = (a->force_bvh == 1 || v1_point) ? 1 : 0;
     fa.dbg = nullptr;
     fa.rec_d = fa.rec_ff = nullptr;
-    fa.geo = nullptr; fa.geo_stride = 0;
+    fa.geo = nullptr; fa.geo_stride = 0; fa.geo_sources = 0;
     // Residual formed by pass 2 itself (round 4): vertex gradient of this call's own forward rows, confocal; k_residual's
     // other chores (clearing the gradient output, the pathlengths) then ride in the grid kernel's first workgroups, and the
     // step holds no residual launch.  Whether the launcher that runs carries them is known after the launch (note.prologue_done).
@@ -682,13 +682,14 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
             if (rc) return rc;
             fa.vis_items = c->vis_items.as<unsigned long long>();
             fa.items_stride = stride;
-            // geometry cache for the pass 2 of THIS call (vertex-gradient modes, confocal): 12 B per ray of the live lists
+            // geometry cache for the pass 2 of THIS call (vertex-gradient modes, confocal): 20 B per ray of the live lists
             static const bool geo_enabled = [] { const char* e = std::getenv("NLOS_GEO_CACHE"); return !e || std::atoi(e) != 0; }();
             if (geo_enabled && !a->sensor && !jitter && (mode == NLOS_MODE_GRADIENT || mode == NLOS_MODE_GRADIENT_V1 || mode == NLOS_MODE_TRANSIENT)) {
-                rc = c->geo.ensure(sizeof(float) * 3 * (size_t)L * (size_t)nF * (size_t)spt + 16);
+                rc = c->geo.ensure(sizeof(float) * 5 * (size_t)L * (size_t)nF * (size_t)spt + 16);
                 if (rc) return rc;
                 fa.geo = c->geo.as<float>();
                 fa.geo_stride = nF * spt;
+                fa.geo_sources = L;
             }
         }
         c->vis_key = key;
@@ -739,6 +740,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     if (!skip_pass1) {     // the geometry cache belongs to the visibility generation it was recorded with
         c->geo_gen = (fa.geo && fa.vis && note.vis_items != 0) ? c->vis_gen : 0;
         c->geo_stride = fa.geo_stride;
+        c->geo_sources = fa.geo_sources;
     }
 #ifdef NLOS_FWD_STAMPS
     {
@@ -864,6 +866,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         // reuse_visibility -- by the render that recorded that generation), as item masks (the cache's index)
         ga.geo = (c->vis_is_items && c->geo_gen != 0 && c->geo_gen == c->vis_gen && c->geo.p) ? c->geo.as<float>() : nullptr;
         ga.geo_stride = c->geo_stride;
+        ga.geo_sources = c->geo_sources;
         ga.inline_residual = fused_residual ? 1 : 0;
         ga.res_data = a->data; ga.res_weight = a->weight; ga.res_transient = transient; ga.res_loss_test = a->loss_test;
         ga.diff_scratch = c->diff.as<double>();

@@ -127,9 +127,11 @@ struct ForwardArgs {
     float path_lb, path_res;
     int path_T;
     // Geometry cache pass 1 -> pass 2 (round 4; confocal single-workgroup grid with item masks only): per ray r = li * spt + s
-    // of the bucketed live list the three numbers pass 2 cannot get cheaply -- h and the hit's barycentrics (v, w) of
-    // sample_geo() -- so that pass 2 neither hashes, nor takes square roots, nor repeats the own-face triangle test.
-    float* geo;              // [L, geo_stride, 3] or null
+    // of the bucketed live list the five numbers pass 2 cannot get cheaply -- the sampled direction and the hit's
+    // barycentrics (v, w) of sample_geo() -- so that pass 2 neither hashes nor repeats the own-face triangle test.
+    float* geo;              // [L, geo_stride] float4 (dir.x, dir.y, dir.z, v) followed by [L, geo_stride] float (w): one dwordx4 + one
+                             // dword per ray (five dwords of a 20-byte record cost pass 2 0.29 ms: profiles/r04_ab_geo_cache.log); or null
+    int geo_sources;         // L of the allocation (where the float part starts)
     int geo_stride;          // rays per source the cache holds (F * spt)
     // record pass of the product (row N as L x S): per wall point and sample r = sorted face slot * spt + s, the path
     // length of the leg and its clamped form factor, 0 where the sample is not seen from that wall point
@@ -198,7 +200,7 @@ struct GradientArgs {
     int items_stride;
     uint32_t* vis_scratch;                 // [L, vis_words, F]: where the face-major kernel gets per-face words from item masks
     const float* geo;                      // geometry cache of pass 1 (ForwardArgs::geo; item-mask layout only) or null
-    int geo_stride;
+    int geo_stride, geo_sources;
     // inline_residual = 1: `diff` is scratch, the kernel forms (data - transient)[^3 * 2] * weight itself while it stages a
     // source's row in LDS (row D, smoothed_transient/stratifiedStreamedGradientRenderer.cpp:543-550); the face-major kernel
     // does not, the launcher then runs k_residual into `diff_scratch` first

@@ -110,18 +110,22 @@ __device__ __forceinline__ bool sample_geo(const Face& f, const Tri& tr, V3 o, u
     return true;
 }
 
-// The same Geo from pass 1's geometry cache (h and the hit's barycentrics v, w, bit for bit what sample_geo() computed):
-// the hit point is rebuilt from them, the direction is the unit vector towards it -- sample_geo()'s direction towards the
-// SAMPLED point up to the rounding of the hit's barycentrics (1e-7; pass 2 decides nothing, its bins come from h).
+// The same Geo from pass 1's geometry cache: the ray's direction and the hit's barycentrics (v, w), bit for bit what
+// sample_geo() computed; h is rebuilt from them with sample_geo()'s own expressions (the same inputs, correctly rounded
+// operations: the same bits).  (A 12-byte record of h, v, w with the direction taken as the unit vector towards the hit point
+// was built first: for rays that graze their face the hit's barycentrics -- and with them that direction -- carry the
+// 1 / |cos| error of the triangle test, and the gradient moved by up to 7e-5 of its norm in the sweep; pass 2 must see the
+// SAMPLED direction, as the reference's does.)
 template <int FEAT>
-__device__ __forceinline__ void cached_geo(const Face& f, V3 o, float h, float hv, float hw, const float* __restrict__ vn,
+__device__ __forceinline__ void cached_geo(const Face& f, V3 o, V3 dir, float hv, float hw, const float* __restrict__ vn,
                                            const float* __restrict__ alb, Geo& g) {
     g.v = hv;
     g.w = hw;
     g.u = 1.0f - g.v - g.w;
     const V3 q = bary(g.u, f.p0, g.v, f.p1, g.w, f.p2);
-    g.h = h;
-    g.dir = (q - o) * __builtin_amdgcn_rcpf(h);
+    const V3 dq = q - o;
+    g.h = sqrtf(dot(dq, dq));
+    g.dir = dir;
     g.n = f.fn;
     if (FEAT & FEAT_VN) {
         g.n = bary(g.u, ld3(vn + 3 * (size_t)f.i0), g.v, ld3(vn + 3 * (size_t)f.i1), g.w,
