@@ -377,7 +377,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     // item-mask layout of the visibility cache (launcher: single-workgroup grid, confocal; then a.vis == nullptr)
     // geometry cache for pass 2 (confocal renders that record item masks: its index is the item masks' ray index)
     float* const geo_l = (!TILED && NCM == 0 && a.geo && a.vis_items) ? a.geo + 4 * (size_t)l * (size_t)a.geo_stride : nullptr;
-    float* const geo_w = geo_l ? a.geo + 4 * (size_t)a.geo_sources * (size_t)a.geo_stride + (size_t)l * (size_t)a.geo_stride : nullptr;
+    float* const geo_w = geo_l ? a.geo + 4 * (size_t)a.geo_sources * (size_t)a.geo_stride + 2 * (size_t)l * (size_t)a.geo_stride : nullptr;
     // (the laser pass of non-confocal pairs records the pair's accepted samples the same way, round 4)
     unsigned long long* const vitems = (!TILED && (NCM == 0 || NCM == 2) && a.vis_items) ? a.vis_items + (size_t)l * (size_t)a.items_stride : nullptr;
 #ifdef NLOS_FWD_STAMPS
@@ -946,7 +946,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     bin = (int)floorf((2.0f * gg.h - lb) / res);
                     dir = gg.dir;
                     if (geo_l && ok) {
-                        // What pass 2 needs of this sample: the sampled direction and the hit's barycentrics (20 B: float4 + float),
+                        // What pass 2 needs of this sample: the sampled direction, the hit's barycentrics and h (24 B: float4 + float2),
                         // written HERE, before the trace (the barycentrics are dead afterwards; an occluded ray's entry is never
                         // read).  Record of (live-list entry li, stratum s) at [s][li]: pass 2 -- one lane per entry, one stratum
                         // per trip -- reads 64 consecutive records per load and every cache line once.  Streaming stores here and
@@ -962,7 +962,9 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                         f4_t* gp = reinterpret_cast<f4_t*>(geo_l) + at;
                         const f4_t rec = {gg.dir.x, gg.dir.y, gg.dir.z, gg.v};
                         __builtin_nontemporal_store(rec, gp);
-                        __builtin_nontemporal_store(gg.w, geo_w + at);
+                        typedef float f2_t __attribute__((ext_vector_type(2)));
+                        const f2_t rec2 = {gg.w, gg.h};
+                        __builtin_nontemporal_store(rec2, reinterpret_cast<f2_t*>(geo_w) + at);
                     }
                 }
             } else if (NCM == 3) {

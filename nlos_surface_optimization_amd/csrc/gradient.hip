@@ -105,7 +105,8 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
         // pass 1's geometry cache (vertex-gradient modes of confocal renders): h and the hit's barycentrics per ray of the live list
         typedef float f4_t __attribute__((ext_vector_type(4)));
         const f4_t* geo_l = GEO ? reinterpret_cast<const f4_t*>(a.geo) + (size_t)l * (size_t)a.geo_stride : nullptr;
-        const float* geo_w = GEO ? a.geo + 4 * (size_t)a.geo_sources * (size_t)a.geo_stride + (size_t)l * (size_t)a.geo_stride : nullptr;
+        typedef float f2_t __attribute__((ext_vector_type(2)));
+        const f2_t* geo_w = GEO ? reinterpret_cast<const f2_t*>(a.geo + 4 * (size_t)a.geo_sources * (size_t)a.geo_stride) + (size_t)l * (size_t)a.geo_stride : nullptr;
         const int n_src = it_l ? (int)it_l[0] : F;
         // faces with at least one accepted sample, compacted in order (pass 1 left the masks)
         for (int b = wave; b < nblocks; b += nwaves) {
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                 // GEO: the record of the NEXT accepted sample is requested one sample ahead (a dependent load per
                 // sample in front of its arithmetic left the kernel waiting: 0.558 -> 0.503 ms only, profiles/r04_ab_geo_cache.log)
                 f4_t nrec = {0.0f, 0.0f, 0.0f, 0.0f};
-                float nw = 0.0f;
+                f2_t nw = {0.0f, 0.0f};
                 if (GEO && word) {
                     const size_t at = (size_t)(__ffs(word) - 1) * (size_t)F + (size_t)e;      // [stratum][live-list entry]
                     nrec = __builtin_nontemporal_load(geo_l + at);
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                     word &= word - 1;
                     const int s = (wi << 5) + bit;
                     const V3 cdir = mk(nrec.x, nrec.y, nrec.z);
-                    const float cv = nrec.w, cw = nw;
+                    const float cv = nrec.w, cw = nw.x, ch = nw.y;
                     if (GEO && word) {
                         const size_t at = (size_t)(__ffs(word) - 1) * (size_t)F + (size_t)e;      // [stratum][live-list entry]
                         nrec = __builtin_nontemporal_load(geo_l + at);
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                     Geo g;
                     float t_self;
                     if (GEO) {
-                        cached_geo<FEAT>(f, o, cdir, cv, cw, a.sc.vertex_normal, a.sc.albedo, g);
+                        cached_geo<FEAT>(f, cdir, cv, cw, ch, a.sc.vertex_normal, a.sc.albedo, g);
                     } else if (!sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, a.sp.lb, a.sp.ub,
                                                  a.sc.vertex_normal, a.sc.albedo, g, t_self))
                         continue;   // cannot happen: pass 1 accepted this sample with the same arithmetic

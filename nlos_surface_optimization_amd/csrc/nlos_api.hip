@@ -682,10 +682,10 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
             if (rc) return rc;
             fa.vis_items = c->vis_items.as<unsigned long long>();
             fa.items_stride = stride;
-            // geometry cache for the pass 2 of THIS call (vertex-gradient modes, confocal): 20 B per ray of the live lists
+            // geometry cache for the pass 2 of THIS call (vertex-gradient modes, confocal): 24 B per ray of the live lists
             static const bool geo_enabled = [] { const char* e = std::getenv("NLOS_GEO_CACHE"); return !e || std::atoi(e) != 0; }();
             if (geo_enabled && !a->sensor && !jitter && (mode == NLOS_MODE_GRADIENT || mode == NLOS_MODE_GRADIENT_V1 || mode == NLOS_MODE_TRANSIENT)) {
-                rc = c->geo.ensure(sizeof(float) * 5 * (size_t)L * (size_t)nF * (size_t)spt + 16);
+                rc = c->geo.ensure(sizeof(float) * 6 * (size_t)L * (size_t)nF * (size_t)spt + 16);
                 if (rc) return rc;
                 fa.geo = c->geo.as<float>();
                 fa.geo_stride = nF * spt;

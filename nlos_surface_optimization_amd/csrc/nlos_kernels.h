@@ -129,8 +129,8 @@ struct ForwardArgs {
     // Geometry cache pass 1 -> pass 2 (round 4; confocal single-workgroup grid with item masks only): per ray r = li * spt + s
     // of the bucketed live list the five numbers pass 2 cannot get cheaply -- the sampled direction and the hit's
     // barycentrics (v, w) of sample_geo() -- so that pass 2 neither hashes nor repeats the own-face triangle test.
-    float* geo;              // [L, geo_stride] float4 (dir.x, dir.y, dir.z, v) followed by [L, geo_stride] float (w): one dwordx4 + one
-                             // dword per ray (five dwords of a 20-byte record cost pass 2 0.29 ms: profiles/r04_ab_geo_cache.log); or null
+    float* geo;              // [L, geo_stride] float4 (dir.x, dir.y, dir.z, v) followed by [L, geo_stride] float2 (w, h): one dwordx4 + one
+                             // dwordx2 per ray (five dwords of a 20-byte record cost pass 2 0.29 ms: profiles/r04_ab_geo_cache.log); or null
     int geo_sources;         // L of the allocation (where the float part starts)
     int geo_stride;          // rays per source the cache holds (F * spt)
     // record pass of the product (row N as L x S): per wall point and sample r = sorted face slot * spt + s, the path

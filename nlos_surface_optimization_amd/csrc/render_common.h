@@ -110,21 +110,18 @@ __device__ __forceinline__ bool sample_geo(const Face& f, const Tri& tr, V3 o, u
     return true;
 }
 
-// The same Geo from pass 1's geometry cache: the ray's direction and the hit's barycentrics (v, w), bit for bit what
-// sample_geo() computed; h is rebuilt from them with sample_geo()'s own expressions (the same inputs, correctly rounded
-// operations: the same bits).  (A 12-byte record of h, v, w with the direction taken as the unit vector towards the hit point
+// The same Geo from pass 1's geometry cache: the ray's direction, the hit's barycentrics (v, w) and h, bit for bit what
+// sample_geo() computed.  (A 12-byte record of h, v, w with the direction taken as the unit vector towards the hit point
 // was built first: for rays that graze their face the hit's barycentrics -- and with them that direction -- carry the
 // 1 / |cos| error of the triangle test, and the gradient moved by up to 7e-5 of its norm in the sweep; pass 2 must see the
 // SAMPLED direction, as the reference's does.)
 template <int FEAT>
-__device__ __forceinline__ void cached_geo(const Face& f, V3 o, V3 dir, float hv, float hw, const float* __restrict__ vn,
+__device__ __forceinline__ void cached_geo(const Face& f, V3 dir, float hv, float hw, float h, const float* __restrict__ vn,
                                            const float* __restrict__ alb, Geo& g) {
     g.v = hv;
     g.w = hw;
     g.u = 1.0f - g.v - g.w;
-    const V3 q = bary(g.u, f.p0, g.v, f.p1, g.w, f.p2);
-    const V3 dq = q - o;
-    g.h = sqrtf(dot(dq, dq));
+    g.h = h;
     g.dir = dir;
     g.n = f.fn;
     if (FEAT & FEAT_VN) {
