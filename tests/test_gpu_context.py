@@ -343,3 +343,20 @@ def test_scene_build_orders_the_faces_by_a_stable_morton_sort(bunny, mannequin, 
     assert (np.diff(key[fid].astype(np.int64)) >= 0).all()
     assert np.array_equal(fid, order)
     r.close()
+
+
+@pytest.mark.parametrize("env", [{"NLOS_GEO_CACHE": "0"}, {"NLOS_FUSE_RESIDUAL": "0"}, {"NLOS_GEO_CACHE": "0", "NLOS_FUSE_RESIDUAL": "0", "NLOS_VIS_ITEMS": "0"}])
+def test_the_step_without_its_round_4_shortcuts_still_matches_the_oracle(env):
+    """The vertex-gradient step reads pass 1's geometry cache and forms the residual inside pass 2 by default; the paths
+    behind them (pass 2 regenerating its samples, the residual launch, per-face visibility words) stay in the library for
+    pairs, jitter, the tiled grid and visibility reuse.  The switches are read once per process, so the smoke render --
+    forward + gradient against the oracle -- runs in a child process with them off."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(root, "__graft_entry__.py"), "smoke"], capture_output=True, text=True,
+                         env=e, timeout=600)
+    assert out.returncode == 0 and "smoke: transient rel-L2" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
