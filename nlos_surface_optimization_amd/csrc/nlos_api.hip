@@ -684,7 +684,10 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
             fa.items_stride = stride;
             // geometry cache for the pass 2 of THIS call (vertex-gradient modes, confocal): 24 B per ray of the live lists
             static const bool geo_enabled = [] { const char* e = std::getenv("NLOS_GEO_CACHE"); return !e || std::atoi(e) != 0; }();
-            if (geo_enabled && !a->sensor && !jitter && (mode == NLOS_MODE_GRADIENT || mode == NLOS_MODE_GRADIENT_V1 || mode == NLOS_MODE_TRANSIENT)) {
+            // (spt <= 8 only: a 64-ray item writes spt segments of 64 / spt consecutive records; at spt = 19 -- the 1 055-face
+            // mannequin -- those are 54-byte pieces, and the streaming stores of partial lines triple pass 1: 1.09 -> 2.80 ms,
+            // profiles/r04_side_bench.log; such renders keep the recomputing pass 2)
+            if (geo_enabled && spt <= 8 && !a->sensor && !jitter && (mode == NLOS_MODE_GRADIENT || mode == NLOS_MODE_GRADIENT_V1 || mode == NLOS_MODE_TRANSIENT)) {
                 rc = c->geo.ensure(sizeof(float) * 6 * (size_t)L * (size_t)nF * (size_t)spt + 16);
                 if (rc) return rc;
                 fa.geo = c->geo.as<float>();

@@ -78,10 +78,11 @@ def main():
         "classes": {"f32_add_mul_fma (2.3 cycles)": f32, "trans_f32 (8.1)": trans, "f64 + cvt + int64 (4.1)": half_known,
                     "int32 + unclassified (2.3 ... 4.1)": mixed},
         "mixed_full_rate_fraction": frac_full, "mixed_fraction_basis": "static ISA histogram" if share is not None else "50/50",
-        "basis": "issue costs: profiles/r03_issue_rates.json (tools/issue_rate.hip, >= 2 waves per SIMD); counters: SQ_INSTS_VALU* "
-                 "(tools/pmc_classes.sh, separate --pmc passes); 1024 SIMDs, engine clock %.3f GHz (%s); the " % (CLOCK / 1e9, "measured on the forward kernel: s_memtime / s_memrealtime, tools/build_stamps.sh" if "NLOS_CLOCK_GHZ" in os.environ else "peak: a lower bound on busy") +
-                 "
-                 "scalar unit serves one SIMD every 4.15 cycles and overlaps with vector issue of other waves",
+        "basis": ("issue costs: profiles/r03_issue_rates.json (tools/issue_rate.hip, >= 2 waves per SIMD); counters: SQ_INSTS_VALU* "
+                  "(tools/pmc_classes.sh, separate --pmc passes); 1024 SIMDs, engine clock %.3f GHz (%s); the scalar unit serves one "
+                  "SIMD every 4.15 cycles and overlaps with vector issue of other waves"
+                  % (CLOCK / 1e9, "measured on the forward kernel: s_memtime / s_memrealtime, tools/build_stamps.sh"
+                     if "NLOS_CLOCK_GHZ" in os.environ else "peak: a lower bound on busy")),
     }
     print(json.dumps(out, indent=1))
 
