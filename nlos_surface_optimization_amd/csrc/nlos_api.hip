@@ -688,11 +688,21 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
             // mannequin -- those are 54-byte pieces, and the streaming stores of partial lines triple pass 1: 1.09 -> 2.80 ms,
             // profiles/r04_side_bench.log; such renders keep the recomputing pass 2)
             if (geo_enabled && spt <= 8 && !a->sensor && !jitter && (mode == NLOS_MODE_GRADIENT || mode == NLOS_MODE_GRADIENT_V1 || mode == NLOS_MODE_TRANSIENT)) {
-                rc = c->geo.ensure(sizeof(float) * 6 * (size_t)L * (size_t)nF * (size_t)spt + 16);
-                if (rc) return rc;
-                fa.geo = c->geo.as<float>();
-                fa.geo_stride = nF * spt;
-                fa.geo_sources = L;
+                // an optimisation, never a reason to fail: bounded (NLOS_GEO_CACHE_MAX_GB, default 32 of the 288 GB) and skipped
+                // when the allocation does not succeed -- pass 2 then regenerates its samples
+                static const size_t geo_max = [] {
+                    const char* e = std::getenv("NLOS_GEO_CACHE_MAX_GB");
+                    const double gb = e ? std::atof(e) : 32.0;
+                    return (size_t)(gb * 1073741824.0);
+                }();
+                const size_t geo_bytes = sizeof(float) * 6 * (size_t)L * (size_t)nF * (size_t)spt + 16;
+                if (geo_bytes <= geo_max && c->geo.ensure(geo_bytes) == NLOS_OK) {
+                    fa.geo = c->geo.as<float>();
+                    fa.geo_stride = nF * spt;
+                    fa.geo_sources = L;
+                } else {
+                    (void)hipGetLastError();
+                }
             }
         }
         c->vis_key = key;

@@ -360,3 +360,14 @@ def test_the_step_without_its_round_4_shortcuts_still_matches_the_oracle(env):
     out = subprocess.run([sys.executable, os.path.join(root, "__graft_entry__.py"), "smoke"], capture_output=True, text=True,
                          env=e, timeout=600)
     assert out.returncode == 0 and "smoke: transient rel-L2" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_geometry_cache_is_bounded_and_optional():
+    """NLOS_GEO_CACHE_MAX_GB = 0: the cache is never allocated and the step regenerates its samples in pass 2 -- the same
+    results (child process: the bound is read once)."""
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    e = dict(os.environ)
+    e["NLOS_GEO_CACHE_MAX_GB"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(root, "__graft_entry__.py"), "smoke"], capture_output=True, text=True,
+                         env=e, timeout=600)
+    assert out.returncode == 0 and "smoke: transient rel-L2" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
