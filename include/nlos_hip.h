@@ -381,7 +381,9 @@ enum {
     NLOS_REASON_LDS           = 3,  /* rows + cell tables leave no room for the cell lists */
     NLOS_REASON_TILE_LIMITS   = 4,  /* more than 1024 tiles, or the tile tables do not fit LDS */
     NLOS_REASON_GGX_PAIRS     = 5,  /* non-confocal pairs in a mode the grid passes do not carry (per-face intensity) */
-    NLOS_REASON_LARGE_MESH    = 6   /* F beyond the single-workgroup grid: tiled */
+    NLOS_REASON_LARGE_MESH    = 6,  /* F beyond the single-workgroup grid: tiled */
+    NLOS_REASON_WINDOW_RANGE  = 7   /* resolution outside [2^-30, 2^30] or a bound beyond 2^29: outside the range on which the
+                                       grid trace's lean division is the IEEE one (csrc/nlos_device.h) */
 };
 typedef struct nlos_path_info {
     int32_t backend;            /* NLOS_PATH_* of pass 1 (NONE if pass 1 was skipped) */

@@ -101,7 +101,8 @@ class PathInfo(ctypes.Structure):
 
 PATH_NAMES = {0: "none", 1: "grid", 2: "tiled-grid", 3: "bvh"}
 REASON_NAMES = {0: "", 1: "force_bvh", 2: "mesh below 64 faces", 3: "rows and cell tables leave no LDS for the cell lists",
-                4: "tile limits", 5: "non-confocal pairs in a mode the grid passes do not carry", 6: "mesh beyond one workgroup's grid"}
+                4: "tile limits", 5: "non-confocal pairs in a mode the grid passes do not carry", 6: "mesh beyond one workgroup's grid",
+                7: "time window outside the grid trace's arithmetic range"}
 GRADIENT_KERNEL_NAMES = {0: "none", 1: "source-major, LDS accumulator", 2: "source-major, global atomics", 3: "face-major"}
 
 

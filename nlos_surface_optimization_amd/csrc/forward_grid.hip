@@ -254,6 +254,11 @@ __device__ __forceinline__ SourceFrame source_frame(const float4* __restrict__ n
     // graze_scale(): plane distance below which a triangle of this scene can be seen at |cos| < 2^-6 (x 1.1)
     const float fx = fmaxf(fabsf(xl), fabsf(xh)), fy = fmaxf(fabsf(yl), fabsf(yh)), fz = fmaxf(fabsf(fr.zr0), fabsf(fr.zr1));
     fr.hmin = sqrtf(fx * fx + fy * fy + fz * fz) * (1.1f / 64.0f);
+    // The grid trace evaluates its square roots, reciprocals and divisions in the lean forms of nlos_device.h, which are the
+    // IEEE results for operands between 2^-60 and 2^60: every vertex at least 2^-29 in front of the wall point and at most
+    // 2^28 away along every axis keeps |p - o|^2, |p - o|, the edge cross products and their reciprocals inside that range.
+    // (A scene outside it -- nanometres or light-seconds in a renderer of metre-sized objects -- takes the BVH query.)
+    fr.ok = fr.ok && fr.zr0 >= 0x1p-29f && fmaxf(fmaxf(fx, fy), fz) <= 0x1p28f;
     return fr;
 }
 
@@ -846,6 +851,8 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     const int n_items = (int)((n_rays + 63u) >> 6);
 #endif
     const uint64_t kbase0 = lg * (uint64_t)F;
+    const uint64_t zbase = sample_zbase(a.sp.seed, kbase0 * (uint64_t)spt);      // sample_st_c(): key = kbase0 spt + (fid spt + s)
+    const float rres = rcp_refined(res);                                          // div_by(x, res, rres) == x / res (launcher: res within the lean range)
     const double inv_spt = 1.0 / (double)spt;
 #ifdef NLOS_FWD_STAMPS
     unsigned long long c_rays = 0, c_pairs = 0, c_iters = 0, c_mt = 0, c_mtw = 0, c_hit = 0, c_occ = 0, c_tested = 0;   // diagnostic build only
@@ -933,17 +940,31 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             bool ok = has_ray;
             if (NCM == 0) {
                 Geo gg;
-                if (ok)
-                    ok = sample_geo<FEAT>(f, tr, o, a.sp.seed, key, lb, ub, a.sc.vertex_normal, a.sc.albedo, gg, t_self);
+                // GRID: the lean forms of sqrt / reciprocal / division (nlos_device.h: the same bits on the range frame_ok
+                // and the launcher guarantee), the draw keyed per source on the scalar unit
+                constexpr bool LEAN = GRID;
                 if (ok) {
-                    float ff = -dot(gg.n, gg.dir) * dot(on, gg.dir) / gg.h / gg.h;
+                    float S, T;
+                    if (LEAN) sample_st_c(zbase, (uint32_t)f.fid * (uint32_t)spt + (uint32_t)s, S, T);
+                    else sample_st(a.sp.seed, key, S, T);
+                    ok = sample_geo_st<FEAT, LEAN>(f, tr, o, S, T, lb, ub, a.sc.vertex_normal, a.sc.albedo, gg, t_self);
+                }
+                if (ok) {
+                    const float num = -dot(gg.n, gg.dir) * dot(on, gg.dir);
+                    float ff;
+                    if (LEAN && __builtin_expect(fabsf(num) >= kLeanMin && fabsf(num) <= kLeanNumMax, 1)) {
+                        const float rh = rcp_refined(gg.h);
+                        ff = div_by(div_by(num, gg.h, rh), gg.h, rh);
+                    } else {
+                        ff = num / gg.h / gg.h;
+                    }
                     if (a.sp.clamp) {
                         ff = emax0(ff);
                         ok = ff > 0.0f;
                     }
                     val = f.area * gg.alb * ff * ff;
                     if (FEAT & FEAT_GGX) val = val * ggx_eval(a.sp.ggx_alpha, dot(gg.n, -gg.dir));
-                    bin = (int)floorf((2.0f * gg.h - lb) / res);
+                    bin = (int)floorf(LEAN ? div_by(2.0f * gg.h - lb, res, rres) : (2.0f * gg.h - lb) / res);
                     dir = gg.dir;
                     if (geo_l && ok) {
                         // What pass 2 needs of this sample: the sampled direction, the hit's barycentrics and h (24 B: float4 + float2),
@@ -1289,6 +1310,12 @@ __global__ __launch_bounds__(kGridNT, kGridNT / 128) void k_forward_grid(Forward
 // arrays (s_scan 2 KiB, s_bkt 128 B); one byte more and only one workgroup fits a CU (2.4 -> 3.9 ms)
 constexpr size_t kGridLdsBudget = 78 * 1024 - 128 - (kGridNT - 512) * 4;
 
+// The grid trace divides by `res` in the lean form (nlos_device.h: div_by), exact for 2^-30 <= res <= 2^30 and path
+// lengths below 2^29; a time window outside that range is rendered through the BVH back-end (reason 7).
+inline bool lean_params_ok(const SampleParams& sp) {
+    return sp.res >= 0x1p-30f && sp.res <= 0x1p30f && fabsf(sp.lb) <= 0x1p29f && fabsf(sp.ub) <= 0x1p29f;
+}
+
 template <int FEAT, int NCM = 0>
 bool forward_grid_launch(const ForwardArgs& a_in, int rows_in_lds, hipStream_t stream) {
     // visibility cache: item masks where this launch can record them (confocal; the live list is its index), per-face
@@ -1304,6 +1331,7 @@ bool forward_grid_launch(const ForwardArgs& a_in, int rows_in_lds, hipStream_t s
     if (a.force_bvh) { note.reason = 1; return false; }
     if (a.sc.F < 64) { note.reason = 2; return false; }
     if (a.tile_list || a.sc.F > 8191) { note.reason = 6; return false; }              // 13-bit triangle index in the cell entries
+    if (!lean_params_ok(a.sp)) { note.reason = 7; return false; }
 #ifndef NLOS_GRID_RSCALE
 #define NLOS_GRID_RSCALE 0.5f
 #endif
@@ -1369,6 +1397,7 @@ bool forward_tiled_launch(const ForwardArgs& a, int rows_in_lds, hipStream_t str
     LaunchNote& note = tl_note ? *tl_note : scratch_note;
     if (a.force_bvh) { note.reason = 1; return false; }
     if (!a.tile_list || !a.tile_count || !a.live || !a.cov) return false;                      // (reason recorded by the single-workgroup launcher)
+    if (!lean_params_ok(a.sp)) { note.reason = 7; return false; }
     if (a.tiles_x * a.tiles_y > 1024 || a.tiles_x < 1 || a.tiles_y < 1) { note.reason = 4; return false; }
     if ((NCM != 0) != (a.src.sensor != nullptr)) return false;
     uint32_t* const visout = NCM == 1 ? a.vis2 : a.vis;

@@ -61,6 +61,72 @@ __device__ __forceinline__ void sample_st(uint64_t seed, uint64_t k, float& S, f
     T = u32_to_unit((uint32_t)(z >> 32));
 }
 
+// The same draw with the source's part of the key folded in on the scalar unit: for k = k0 + c (k0 wave-uniform, c a
+// 32-bit per-lane count) seed + (k + 1) G = [seed + (k0 + 1) G] + c G  (mod 2^64), so a lane pays one 32 x 64-bit
+// multiply-add instead of forming the 64-bit key, a 64 x 64-bit product and a 64-bit add: five quarter-rate
+// instructions fewer per ray, the same bits.
+__device__ __forceinline__ uint64_t sample_zbase(uint64_t seed, uint64_t k0) { return seed + (k0 + 1ull) * 0x9E3779B97F4A7C15ull; }
+__device__ __forceinline__ void sample_st_c(uint64_t zbase, uint32_t c, float& S, float& T) {
+    uint64_t z = zbase + (uint64_t)c * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    S = u32_to_unit((uint32_t)(z & 0xffffffffull));
+    T = u32_to_unit((uint32_t)(z >> 32));
+}
+
+// ------------------------------------------------ lean correctly rounded sqrt / reciprocal / division
+// hipcc's sqrtf and `/` are correctly rounded for EVERY input: v_sqrt_f32 / v_rcp_f32 (1 ulp) wrapped in a denormal
+// pre-scale, the refinement, an un-scale and an inf / nan / zero fix-up -- 17 instructions per sqrtf, 12 per division,
+// of which only the refinement does anything for operands of ordinary magnitude.  The functions below are that
+// refinement alone: THE SAME BITS as sqrtf(x) / (1.0f / x) / (a / b) for operands whose exponent field lies in
+// [kLeanExpLo, kLeanExpHi] (2^-60 <= |x| < 2^61; sqrt_cr and a numerator of div_*: also zero), proven on the hardware by
+// tools/exact_math_check.hip (all 2^32 bit patterns for the unary functions; 2^33 random + structured pairs for the
+// division, whose sequence is moreover the compiler's own minus v_div_scale / v_div_fixup, which are the identity on
+// that range) -> profiles/r05_exact_math.json, tests/test_gpu_exact_math.py.  Callers guarantee the range
+// (forward_grid.hip: per source through `frame_ok`, per lane by a guard that branches to the IEEE form).
+constexpr uint32_t kLeanExpLo = 127 - 60, kLeanExpHi = 127 + 60;
+constexpr float kLeanMin = 0x1p-60f, kLeanMax = 0x1p60f;
+// second regime of the division (the form factor num / h / h and the bin (2 h - lb) / res): numerator fields
+// [127 - 90, 127 + 60] (or zero) over denominator fields [127 - 30, 127 + 30] -- quotients stay normal, none of
+// v_div_scale's conditions is met (numerator field > 23, exponent difference < 96), swept like the first
+constexpr uint32_t kLeanNumLo = 127 - 90, kLeanNumHi = 127 + 60, kLeanDenLo = 127 - 30, kLeanDenHi = 127 + 30;
+constexpr float kLeanNumMax = 0x1p30f;      // form-factor numerator: <= 2^30 keeps num / h inside the numerator range of the second division
+// v_rsq_f32 and one residual step (candidates with v_sqrt_f32 -- + the compiler's own +-1 ulp test, or + a step with
+// h = rsq / 2 -- are exact on the same range and cost 34 / 23 issue cycles against 17 for this one)
+__device__ __forceinline__ float sqrt_cr(float x) {
+    float g = __builtin_amdgcn_rsqf(x);
+    float y = x * g, h = 0.5f * g;
+    float r = __fmaf_rn(-y, y, x);
+    return __fmaf_rn(r, h, y);
+}
+// the same for x in {0} u [2^-60, 2^61): the reciprocal square root of max(x, 2^-60) leaves 0 * g = 0 for x = 0
+__device__ __forceinline__ float sqrt_cr0(float x) {
+    float g = __builtin_amdgcn_rsqf(fmaxf(x, kLeanMin));
+    float y = x * g, h = 0.5f * g;
+    float r = __fmaf_rn(-y, y, x);
+    return __fmaf_rn(r, h, y);
+}
+__device__ __forceinline__ float rcp_cr(float x) {
+    float q = __builtin_amdgcn_rcpf(x);
+    float e = __fmaf_rn(-x, q, 1.0f);
+    return __fmaf_rn(e, q, q);
+}
+// a / b in two halves, for a denominator shared by several divisions (or wave-uniform): r = rcp_refined(b) once
+__device__ __forceinline__ float rcp_refined(float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    float e = __fmaf_rn(-b, r, 1.0f);
+    return __fmaf_rn(e, r, r);
+}
+__device__ __forceinline__ float div_by(float a, float b, float r) {
+    float q = a * r;
+    float e = __fmaf_rn(-b, q, a);
+    q = __fmaf_rn(e, r, q);
+    e = __fmaf_rn(-b, q, a);
+    return __fmaf_rn(e, r, q);
+}
+__device__ __forceinline__ float div_lean(float a, float b) { return div_by(a, b, rcp_refined(b)); }
+
 // ------------------------------------------------------------ triangle record
 // 64-byte record (one cache-line half, 4 x dwordx4), sorted (Morton) order:
 //   p0, e1 = p0-p1, e2 = p2-p0, ng = e2 x e1, zmin (smallest vertex z), original face id
@@ -111,6 +177,8 @@ __device__ __forceinline__ float flipsign(float x, bool neg) { return neg ? -x :
 
 // Embree-3 style Moeller-Trumbore with tnear = 0, tfar = inf.  On a hit writes
 // t and the barycentrics (u -> 2nd vertex, v -> 3rd vertex).
+// LEAN: the reciprocal as rcp_cr() where |den| lies in its range (the rare lane outside takes the IEEE division): same bits.
+template <bool LEAN = false>
 __device__ __forceinline__ bool tri_test(const Tri& tr, V3 o, V3 d, float& t, float& u, float& v) {
     V3 c = tr.p0 - o;
     V3 r = cross(c, d);
@@ -124,7 +192,9 @@ __device__ __forceinline__ bool tri_test(const Tri& tr, V3 o, V3 d, float& t, fl
     float Tn = flipsign(dot(tr.ng, c), sg);
     if (!(0.0f < Tn)) return false;
     if (!(aden >= tr.gmin)) return false;          // grazing rule
-    float rcp = 1.0f / aden;
+    float rcp;
+    if (LEAN && __builtin_expect(aden >= kLeanMin && aden <= kLeanMax, 1)) rcp = rcp_cr(aden);
+    else rcp = 1.0f / aden;
     u = U * rcp;
     v = Vv * rcp;
     t = Tn * rcp;

@@ -77,28 +77,29 @@ struct Geo {
 // Row S + the own-face part of row I: stratified sample -> ray -> hit on face j.
 // Returns false if the ray misses its own triangle (edge rounding) or the path
 // length is outside [lb/2, ub/2].
-template <int FEAT>
-__device__ __forceinline__ bool sample_geo(const Face& f, const Tri& tr, V3 o, uint64_t seed, uint64_t k,
-                                           float lb, float ub, const float* __restrict__ vn,
-                                           const float* __restrict__ alb, Geo& g, float& t_self) {
-    float S, T;
-    sample_st(seed, k, S, T);
-    float sq = sqrtf(T);
+// LEAN (the grid kernel's trace: every vertex of the scene lies between 2^-29 and 2^28 in front of / around the wall
+// point, forward_grid.hip: source_frame()): the square roots and reciprocals as sqrt_cr() / rcp_cr() (nlos_device.h) --
+// the same bits for 40 % of the instructions; the draw comes keyed as (zbase, c), see sample_st_c().
+template <int FEAT, bool LEAN = false>
+__device__ __forceinline__ bool sample_geo_st(const Face& f, const Tri& tr, V3 o, float S, float T,
+                                              float lb, float ub, const float* __restrict__ vn,
+                                              const float* __restrict__ alb, Geo& g, float& t_self) {
+    float sq = LEAN ? sqrt_cr0(T) : sqrtf(T);
     float u = 1 - sq;
     float v = (1 - S) * sq;
     float w = S * sq;
     V3 p = bary(u, f.p0, v, f.p1, w, f.p2);
     V3 d = p - o;
-    float rs = 1.0f / sqrtf(dot(d, d));
+    float rs = LEAN ? rcp_cr(sqrt_cr(dot(d, d))) : 1.0f / sqrtf(dot(d, d));
     g.dir = d * rs;
     float hu, hv;
-    if (!tri_test(tr, o, g.dir, t_self, hu, hv)) return false;
+    if (!tri_test<LEAN>(tr, o, g.dir, t_self, hu, hv)) return false;
     g.v = hu;
     g.w = hv;
     g.u = 1.0f - g.v - g.w;
     V3 q = bary(g.u, f.p0, g.v, f.p1, g.w, f.p2);
     V3 dq = q - o;
-    g.h = sqrtf(dot(dq, dq));
+    g.h = LEAN ? sqrt_cr(dot(dq, dq)) : sqrtf(dot(dq, dq));
     if (!((g.h <= ub / 2.0f) && (g.h >= lb / 2.0f))) return false;
     g.n = f.fn;
     if (FEAT & FEAT_VN) {
@@ -108,6 +109,14 @@ __device__ __forceinline__ bool sample_geo(const Face& f, const Tri& tr, V3 o, u
     g.alb = 1.0f;
     if (FEAT & FEAT_ALB) g.alb = g.u * alb[f.i0] + g.v * alb[f.i1] + g.w * alb[f.i2];
     return true;
+}
+template <int FEAT>
+__device__ __forceinline__ bool sample_geo(const Face& f, const Tri& tr, V3 o, uint64_t seed, uint64_t k,
+                                           float lb, float ub, const float* __restrict__ vn,
+                                           const float* __restrict__ alb, Geo& g, float& t_self) {
+    float S, T;
+    sample_st(seed, k, S, T);
+    return sample_geo_st<FEAT, false>(f, tr, o, S, T, lb, ub, vn, alb, g, t_self);
 }
 
 // The same Geo from pass 1's geometry cache: the ray's direction, the hit's barycentrics (v, w) and h, bit for bit what
