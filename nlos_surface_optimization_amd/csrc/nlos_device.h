@@ -235,7 +235,10 @@ __device__ __forceinline__ bool tri_occludes(const Tri& tr, V3 o, V3 d, float t_
     bool occ = false;
     if (valid) {
         const float gmin = kGrazeRatio * reinterpret_cast<const float*>(tris)[4 * (kTriStride * k + 3) + 2];
-        float t = Tn * (1.0f / aden);
+        // (one lane in twenty reaches this block, but nearly every wave does: the reciprocal in its lean form, same bits)
+        float t;
+        if (__builtin_expect(aden >= kLeanMin && aden <= kLeanMax, 1)) t = Tn * rcp_cr(aden);
+        else t = Tn * (1.0f / aden);
         occ = (aden >= gmin) && t < t_self;
         if (aden >= gmin && t == t_self) occ = face_id[k] < self_fid;
     }
