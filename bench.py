@@ -482,6 +482,13 @@ def run_rank(args, backend):
     # per-kernel durations: HIP events recorded on the launch stream inside the timed region
     kt = np.array(r.timing_mean_ms()[0]) if hasattr(r, "timing_mean_ms") else np.zeros(4)
     path = r.last_path(count=True) if hasattr(r, "last_path") else None
+    # what one step does with its L * F * spt surface samples (pass 1's own counters, nlos_path_info): faces a wall point
+    # sees from behind are dropped before sampling, so fewer rays are traced than samples are counted in `value`
+    rays = [(path or {}).get("rays_traced", -1), (path or {}).get("samples_accepted", -1)]
+    if world > 1:
+        tr_ = torch.tensor([float(x) for x in rays] + [1.0 if rays[0] >= 0 else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tr_, op=dist.ReduceOp.SUM)
+        rays = [int(tr_[0].item()), int(tr_[1].item())] if int(tr_[2].item()) == world else [-1, -1]
 
     # sustained figure: the K timed steps are a short burst at boost clock; a loop of >= sustain-seconds shows
     # what a long optimisation sees (DVFS give-back, MI355X_MICROARCH.md)
@@ -505,7 +512,7 @@ def run_rank(args, backend):
         for part in ndist.PARTITIONS:
             share[part] = {}
             for n_split in (2, 4, 8):
-                per = []
+                per, per_k = [], []
                 for k in range(n_split):
                     ksl, klo, kstride = ndist.shard_slice(L_total, k, n_split, part)
                     o_k, n_k = origin[ksl].contiguous(), normal[ksl].contiguous()
@@ -518,13 +525,19 @@ def run_rank(args, backend):
                     for _ in range(3):
                         step_k()
                     backend.sync()
+                    if hasattr(r, "timing_reset"):
+                        r.timing_reset()
                     t0 = time.perf_counter()
                     for _ in range(args.share_steps):
                         step_k()
                     backend.sync()
                     per.append(1e3 * (time.perf_counter() - t0) / args.share_steps)
+                    if hasattr(r, "timing_mean_ms"):
+                        per_k.append([round(float(x), 5) for x in r.timing_mean_ms()[0]])
                 share[part][str(n_split)] = {"per_rank_ms": per, "max_ms": max(per), "spread": (max(per) - min(per)) / min(per),
-                                             "efficiency_without_collective": (1e3 * elapsed / args.steps) / (n_split * max(per))}
+                                             "efficiency_without_collective": (1e3 * elapsed / args.steps) / (n_split * max(per)),
+                                             # HIP-event means per rank block: [bvh_build, k_forward, k_residual, k_gradient] ms
+                                             "per_rank_kernel_ms": per_k}
 
     if diagnostic:
         if rank == 0:
@@ -540,6 +553,10 @@ def run_rank(args, backend):
         if path is not None:
             cfg["path"] = path
         out = {
+            # schema 5 (round 5): + rays_traced_per_step / accepted_per_step / traced_rays_per_s, roofline.step_model,
+            # roofline.valu_issue_frac, roofline.pass2, strong_share[partition][N].per_rank_kernel_ms.  Schema 4 (round 4):
+            # strong_share nested as [partition][N] (default partition strided), as_rank.sources a count.
+            "schema": 5,
             "metric": METRIC,
             "value": samples_per_step * args.steps / elapsed,
             "unit": "samples/s",
@@ -560,6 +577,17 @@ def run_rank(args, backend):
         }
         if parity is not None:
             out["parity"] = parity
+        if rays[0] >= 0:
+            # `value` counts SURFACE SAMPLES (the metric's unit: sources x faces x strata, the reference's loop count); these say
+            # how many of them pass 1 traces a ray for and how many end up in a bin
+            out["rays_traced_per_step"] = rays[0]
+            out["accepted_per_step"] = rays[1]
+            out["traced_rays_per_s"] = rays[0] * args.steps / elapsed
+            out["samples_note"] = ("of the %d surface samples of a step, %d (%.1f %%) are traced: the faces a wall point sees from "
+                                   "behind contribute exactly 0 under the clamped form factor and are dropped per (source, face) "
+                                   "before sampling; %d (%.1f %%) are found visible and binned" % (
+                                       samples_per_step, rays[0], 100.0 * rays[0] / samples_per_step, rays[1],
+                                       100.0 * rays[1] / samples_per_step))
         if args.of > 1:
             out["as_rank"] = {"rank": args.as_rank, "of": args.of, "partition": partition, "first_source": lo, "source_stride": stride, "sources": L,
                               "note": "one GPU timing what rank %d of a %d-rank strong split does per step (no collective); "
@@ -594,6 +622,24 @@ def run_rank(args, backend):
                 roof["hbm_measured_GBps"] = traffic / (kt[dom] * 1e-3) / 1e9
                 roof["hbm_measured_frac"] = roof["hbm_measured_GBps"] / HBM_PEAK_GBS
             roof["build"] = here_stamp
+            # the same model over the whole step (16 + 36/spt B per sample forward, 184 + 36/spt B gradient): the
+            # reference's traffic for this work would exceed the HBM peak at this step time -- the histogram
+            # read-modify-writes, the residual window and the nine gradient accumulations it counts live in LDS and
+            # registers here -- so the step is not priced against HBM at all (see valu_issue_frac)
+            step_bytes = (200.0 + 72.0 / spt) * local_samples
+            roof["step_model"] = {"algorithmic_bytes_per_step": step_bytes, "GBps": step_bytes / (ms * 1e-3) / 1e9,
+                                  "frac_of_hbm": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "note": "exceeds peak where > 1: a model of the reference's traffic, not of this path's"}
+            # the ceiling that binds the dominant kernel, first-class: VALU issue slots used / available (central estimate of
+            # the weighted issue model, profiles/pmc_summary.json of THIS build; None when the committed counters are stale)
+            roof["valu_issue_frac"] = (issue or {}).get("valu_busy", {}).get("central") if isinstance((issue or {}).get("valu_busy"), dict) else None
+            pmc_all = load_pmc_summary() or {}
+            g2 = pmc_all.get("k_gradient") if traffic else None
+            if g2 and kt[3] > 0:
+                roof["pass2"] = {"kernel": "k_gradient", "ms": float(kt[3]), "hbm_bytes_per_launch": g2.get("hbm_bytes_per_launch"),
+                                 "hbm_GBps": (g2.get("hbm_bytes_per_launch") or 0.0) / (kt[3] * 1e-3) / 1e9,
+                                 "valu_busy": (g2.get("valu_busy") or {}).get("central"),
+                                 "active_lane_frac": g2.get("active_lane_frac")}
             if issue:
                 # the ceiling that binds: VALU issue slots (from the committed PMC passes of this same command on this
                 # same build), or {"stale": ...} when the committed counters belong to other kernel sources

@@ -396,8 +396,14 @@ typedef struct nlos_path_info {
                                    atomics, 3 face-major */
     /* per-workgroup outcomes of the grid launches (sources, or (source, tile) pairs); -1 unless counted */
     int64_t workgroups, coarsened, big_lds, bvh_queries;
+    /* what pass 1 did with the L * F * spt surface samples of the render (summed over its sources); -1 unless counted:
+     * single-workgroup grid with item masks only (confocal and pairs, spt <= 32).  `rays_traced`: samples that hit their
+     * own face inside the time window with a non-zero form factor and went through the occlusion query (faces the wall
+     * point sees from behind are dropped before sampling: exact under the clamped form factor); `samples_accepted`: the
+     * ones found visible and binned. */
+    int64_t rays_traced, samples_accepted;
 } nlos_path_info;
-/* count_workgroups != 0 synchronises the device and fills the four counters from the launch's flags:
+/* count_workgroups != 0 synchronises the device and fills the counters from the launch's flags and the item-mask headers:
  * `coarsened` restarted on a coarser grid inside the kernel, `big_lds` were redone by the second launch
  * with the whole CU's LDS, `bvh_queries` traced their rays through the in-kernel BVH query (scene not
  * strictly in front of the wall point, or cell lists that fit nowhere). */

@@ -96,6 +96,8 @@ class PathInfo(ctypes.Structure):
         ("coarsened", ctypes.c_int64),
         ("big_lds", ctypes.c_int64),
         ("bvh_queries", ctypes.c_int64),
+        ("rays_traced", ctypes.c_int64),
+        ("samples_accepted", ctypes.c_int64),
     ]
 
 

@@ -455,7 +455,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
         for (int i = tid; i < nbins; i += NT) s_row[i] = 0.0;
     for (int i = tid; i <= ncell; i += NT) s_cell[i] = 0u;
     for (int i = tid; i < R2 * R2; i += NT) s_zc[i] = 0u;
-    if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = frame_ok ? 0 : 1; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[4] = 0; }
+    if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = frame_ok ? 0 : 1; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[4] = 0; s_ctl[5] = 0; s_ctl[6] = 0; }
     if (tid < 32) s_bkt[tid] = 0u;
     __syncthreads();
 
@@ -863,6 +863,9 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
 #define TMARK() do { } while (0)
 #define TACC(v) do { } while (0)
 #endif
+    // what this source did (nlos_ctx_last_path, bench.py: rays_traced_per_step / accepted_per_step): rays that reached the
+    // occlusion query and samples that were binned, counted per wave on the scalar unit
+    int n_traced = 0, n_accepted = 0;
     uint32_t* wq = s_queue + wave * (kQueueCap + 1);     // this wave's pair queue (aliases the build-phase tables) + dump slot
     uint32_t* wocc = s_queue + nwaves * (kQueueCap + 1) + wave * 2;  // this wave's 64-bit occlusion mask
 
@@ -1049,6 +1052,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 ok = dir.z > 0.0f ? (ti == tile_x && tj == tile_y) : tile == 0;
             }
             if (!ok) dir = mk(0.0f, 0.0f, 1.0f);
+            if (vitems) n_traced += __popcll(__ballot(ok));
             if (!GRID && ok)
                 ok = !occluded(a.sc.nodes, a.sc.n_nodes, a.sc.tris, a.sc.face_id, o, dir, t_self, jg, fid);
 
@@ -1229,7 +1233,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     else if (bits) { pend_at = at | 0x80000000u; pend_bits = bits << (s & 31); }
                 }
             }
-            if (vitems) { pend_item = b; pend_mask = __ballot(ok); }
+            if (vitems) { pend_item = b; pend_mask = __ballot(ok); n_accepted += __popcll(pend_mask); }
             TACC(th);
         }
         if (visout) flush_pending();
@@ -1267,7 +1271,13 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     // big-LDS launch only looks for the value 1
     // Every first-pass workgroup of the one-workgroup-per-source launch writes its code on its way out (0 = plain
     // grid), so the array needs no memset before the launch.
-    if (vitems && tid == 0) vitems[0] = (unsigned long long)n_live;      // pass 2 walks the live list (g_live stays valid)
+    if (vitems) {
+        // header word of the source's item masks: [15:0] live faces (pass 2 walks the live list; g_live stays valid),
+        // [39:16] rays traced, [63:40] samples accepted (F <= 8191, F spt < 2^24 on this path)
+        if (lane == 0) { atomicAdd(&s_ctl[5], n_traced); atomicAdd(&s_ctl[6], n_accepted); }
+        __syncthreads();
+        if (tid == 0) vitems[0] = (unsigned long long)n_live | ((unsigned long long)(uint32_t)s_ctl[5] << 16) | ((unsigned long long)(uint32_t)s_ctl[6] << 40);
+    }
     if (a.retry && tid == 0) {
         if (!TILED && pass == 0) a.retry[blockIdx.x] = COARSE ? 0x100 + R : (use_grid ? 0 : 0x200);
         else if (COARSE) a.retry[blockIdx.x] = 0x100 + R;

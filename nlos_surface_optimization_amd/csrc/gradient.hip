@@ -15,7 +15,7 @@ namespace nlos {
 namespace {
 
 // accepted-sample bits (spt <= 32) of live-list entry li out of the source's item masks: ray r = li * spt + s is bit r & 63
-// of item r >> 6 (items[0] = number of live faces, the masks follow)
+// of item r >> 6 (items[0] = header: number of live faces in its low 16 bits -- forward_grid.hip --, the masks follow)
 __device__ __forceinline__ uint32_t item_bits(const unsigned long long* __restrict__ items, int li, int spt) {
     const uint32_t r0 = (uint32_t)li * (uint32_t)spt;
     const uint32_t w = r0 >> 6, sh = r0 & 63u;
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_items_to_words(const unsigned long long
     for (int j = threadIdx.x; j < F; j += blockDim.x) w[j] = 0u;
     __syncthreads();
     const unsigned long long* it = items + (size_t)l * (size_t)items_stride;
-    const int n_live = (int)it[0];
+    const int n_live = (int)(it[0] & 0xffffull);
     for (int li = threadIdx.x; li < n_live; li += blockDim.x) w[live[(size_t)l * F + li]] = item_bits(it, li, spt);
 }
 
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
         const f4_t* geo_l = GEO ? reinterpret_cast<const f4_t*>(a.geo) + (size_t)l * (size_t)a.geo_stride : nullptr;
         typedef float f2_t __attribute__((ext_vector_type(2)));
         const f2_t* geo_w = GEO ? reinterpret_cast<const f2_t*>(a.geo + 4 * (size_t)a.geo_sources * (size_t)a.geo_stride) + (size_t)l * (size_t)a.geo_stride : nullptr;
-        const int n_src = it_l ? (int)it_l[0] : F;
+        const int n_src = it_l ? (int)(it_l[0] & 0xffffull) : F;
         // faces with at least one accepted sample, compacted in order (pass 1 left the masks)
         for (int b = wave; b < nblocks; b += nwaves) {
             const int j = (b << 6) + lane;
@@ -525,8 +525,9 @@ bool gradient_fm_launch(const GradientArgs& a, hipStream_t stream) {
                        (size_t)kFmBatch * kFmChunk * 2 + 16;
     if (lds > 80 * 1024) return false;
     const int nchunks = (a.sc.F + kFmChunk - 1) / kFmChunk;
-    // enough workgroups to fill the chip (256 CUs x 2), sources in multiples of the batch
-    int groups = (1024 + nchunks - 1) / nchunks;
+    // enough workgroups to fill the chip (four per CU: 1024 on the 256 CUs of an unpartitioned MI355X), sources in multiples of the batch
+    const int want = 4 * device_cu_count();
+    int groups = (want + nchunks - 1) / nchunks;
     int per = (a.src.L + groups - 1) / groups;
     per = ((per + kFmBatch - 1) / kFmBatch) * kFmBatch;
     if (per < kFmBatch) per = kFmBatch;
@@ -661,7 +662,7 @@ void launch_gradient(const GradientArgs& a_in, hipStream_t stream) {
     int per_cu = (int)(160 * 1024 / (lds + 64));
     if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;
-    int grid = 256 * per_cu;
+    int grid = device_cu_count() * per_cu;
     if (grid > a.src.L) grid = a.src.L;
     // a single workgroup per CU: give it the sixteen waves two workgroups would have had
     static const int wide_ok = [] { const char* e = std::getenv("NLOS_GRAD_WIDE"); return e ? std::atoi(e) : 1; }();

@@ -54,6 +54,17 @@ struct DevBuf {
         if (p) { hipError_t e = hipFree(p); (void)e; }
         p = nullptr; cap = 0;
     }
+    // For scratch that is an optimisation, never a reason to fail (the geometry cache): exactly `bytes`, allocated BEFORE the
+    // old buffer is given up -- a growth that does not succeed leaves what worked in place -- and without touching the
+    // last-error string.  false: no buffer of that size.
+    bool try_ensure(size_t bytes) {
+        if (bytes <= cap) return true;
+        void* q = nullptr;
+        if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (p) { hipError_t e = hipFree(p); (void)e; }
+        p = q; cap = bytes;
+        return true;
+    }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -94,6 +105,7 @@ struct nlos_ctx {
     // what the last render did (nlos_ctx_last_path)
     nlos_path_info path;
     int path_retry_workgroups = 0;
+    int path_items_sources = 0;      // > 0: the last pass 1 recorded item masks for this many sources (their headers carry its ray counts)
     // deferred device-side status (bad face index seen by the scene build): copied to pinned host memory behind
     // the build, looked at -- without synchronising -- by the next nlos_render, or by nlos_ctx_check
     int* h_status = nullptr;
@@ -460,6 +472,18 @@ void nlos_render_args_init(nlos_render_args* a) {
 
 static int render_product(nlos_ctx* c, const nlos_render_args* a, void* stream);
 
+// argument checks shared by nlos_render and the product's fast path (which does not go through nlos_render's own):
+// time window, temporal kernel, outputs.  0 or a failed status.
+static int check_window_and_taps(const nlos_render_args* a) {
+    if (!(a->resolution > 0.0f) || !(a->upper_bound > a->lower_bound))
+        if (a->mode != NLOS_MODE_INTENSITY) return fail(NLOS_ERR_ARG, "nlos_render: need resolution > 0 and upper_bound > lower_bound");
+    if (a->refine_scale < 1 || a->sigma_bin < 1) return fail(NLOS_ERR_ARG, "nlos_render: refine_scale and sigma_bin must be >= 1");
+    // the temporal kernel's taps are staged in LDS by the smoothing and gradient kernels
+    if ((long long)4 * a->refine_scale * a->sigma_bin + a->refine_scale > 2048 || a->jitter_length > 2048)
+        return fail(NLOS_ERR_ARG, "nlos_render: temporal kernel longer than 2048 taps (4 * refine_scale * sigma_bin + 1, or jitter_length)");
+    return NLOS_OK;
+}
+
 int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     if (c && a && a->n_sensors > 0) return render_product(c, a, stream);
     if (!c || !a) return fail(NLOS_ERR_ARG, "nlos_render: NULL ctx/args");
@@ -468,12 +492,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     if (!a->vertices || !a->faces) return fail(NLOS_ERR_ARG, "nlos_render: vertices/faces are NULL");
     if (a->L > 0 && (!a->origin || !a->normal)) return fail(NLOS_ERR_ARG, "nlos_render: origin/normal are NULL");
     if (a->num_samples <= 0) return fail(NLOS_ERR_ARG, "nlos_render: num_samples must be positive");
-    if (!(a->resolution > 0.0f) || !(a->upper_bound > a->lower_bound) )
-        if (a->mode != NLOS_MODE_INTENSITY) return fail(NLOS_ERR_ARG, "nlos_render: need resolution > 0 and upper_bound > lower_bound");
-    if (a->refine_scale < 1 || a->sigma_bin < 1) return fail(NLOS_ERR_ARG, "nlos_render: refine_scale and sigma_bin must be >= 1");
-    // the temporal kernel's taps are staged in LDS by the smoothing and gradient kernels
-    if ((long long)4 * a->refine_scale * a->sigma_bin + a->refine_scale > 2048 || a->jitter_length > 2048)
-        return fail(NLOS_ERR_ARG, "nlos_render: temporal kernel longer than 2048 taps (4 * refine_scale * sigma_bin + 1, or jitter_length)");
+    if (int rcw = check_window_and_taps(a)) return rcw;
     const int mode = a->mode;
     const bool needs_grad = mode == NLOS_MODE_GRADIENT || mode == NLOS_MODE_GRAD_ALBEDO || mode == NLOS_MODE_GRAD_ALPHA ||
                             mode == NLOS_MODE_GRADIENT_V1;
@@ -522,6 +541,8 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     struct NoteScope { NoteScope(nlos::LaunchNote* n) { nlos::tl_note = n; } ~NoteScope() { nlos::tl_note = nullptr; } } note_scope(&note);
     std::memset(&c->path, 0, sizeof(c->path));
     c->path.workgroups = c->path.coarsened = c->path.big_lds = c->path.bvh_queries = -1;
+    c->path.rays_traced = c->path.samples_accepted = -1;
+    c->path_items_sources = 0;
     c->path_retry_workgroups = 0;
 
     mark(c, 0, st);
@@ -688,23 +709,30 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
             // mannequin -- those are 54-byte pieces, and the streaming stores of partial lines triple pass 1: 1.09 -> 2.80 ms,
             // profiles/r04_side_bench.log; such renders keep the recomputing pass 2)
             if (geo_enabled && spt <= 8 && !a->sensor && !jitter && (mode == NLOS_MODE_GRADIENT || mode == NLOS_MODE_GRADIENT_V1 || mode == NLOS_MODE_TRANSIENT)) {
-                // an optimisation, never a reason to fail: bounded (NLOS_GEO_CACHE_MAX_GB, default 32 of the 288 GB) and skipped
-                // when the allocation does not succeed -- pass 2 then regenerates its samples
-                static const size_t geo_max = [] {
-                    const char* e = std::getenv("NLOS_GEO_CACHE_MAX_GB");
-                    const double gb = e ? std::atof(e) : 32.0;
-                    return (size_t)(gb * 1073741824.0);
-                }();
+                // an optimisation, never a reason to fail: bounded -- NLOS_GEO_CACHE_MAX_GB if set, else 32 GB or half of what
+                // the device has free, whichever is less -- and skipped when the allocation does not succeed (pass 2 then
+                // regenerates its samples).  DevBuf::try_ensure: exact size, the old buffer survives a failed growth, the
+                // last-error string stays clean.
+                static const double geo_env_gb = [] { const char* e = std::getenv("NLOS_GEO_CACHE_MAX_GB"); return e ? std::atof(e) : -1.0; }();
                 const size_t geo_bytes = sizeof(float) * 6 * (size_t)L * (size_t)nF * (size_t)spt + 16;
-                if (geo_bytes <= geo_max && c->geo.ensure(geo_bytes) == NLOS_OK) {
+                size_t geo_max = (size_t)32 << 30;
+                if (geo_env_gb >= 0.0) {
+                    geo_max = (size_t)(geo_env_gb * 1073741824.0);
+                } else if (geo_bytes > c->geo.cap) {
+                    size_t free_b = 0, total_b = 0;
+                    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) geo_max = std::min(geo_max, (free_b + c->geo.cap) / 2);
+                    else (void)hipGetLastError();
+                }
+                if (geo_bytes <= geo_max && c->geo.try_ensure(geo_bytes)) {
                     fa.geo = c->geo.as<float>();
                     fa.geo_stride = nF * spt;
                     fa.geo_sources = L;
-                } else {
-                    (void)hipGetLastError();
                 }
             }
         }
+        // a pass 1 that records no geometry invalidates whatever the cache held (new visibility generation): a large buffer goes
+        // back to the device (small ones stay: renders of different kinds may alternate, and hipMalloc / hipFree synchronise)
+        if (!skip_pass1 && !fa.geo && c->geo.p && c->geo.cap >= ((size_t)4 << 30)) c->geo.release();
         c->vis_key = key;
         if (!skip_pass1) c->vis_gen = ++c->gen_counter;
     } else {
@@ -750,6 +778,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     c->path_retry_workgroups = note.retry_workgroups;
     if (note.tree_built) c->tree_complete = true;
     if (!skip_pass1 && fa.vis) { c->vis_is_items = note.vis_items != 0; c->vis_items_stride = fa.items_stride; }
+    c->path_items_sources = (!skip_pass1 && fa.vis && note.vis_items != 0 && n_chunks == 1) ? L : 0;
     if (!skip_pass1) {     // the geometry cache belongs to the visibility generation it was recorded with
         c->geo_gen = (fa.geo && fa.vis && note.vis_items != 0) ? c->vis_gen : 0;
         c->geo_stride = fa.geo_stride;
@@ -953,6 +982,12 @@ static int render_product(nlos_ctx* c, const nlos_render_args* a, void* stream) 
         return fail(NLOS_ERR_ARG, "nlos_render (product): residual / visibility reuse / jitter / unclamped form factors are not offered");
     if (a->F <= 0 || a->V <= 0 || !a->vertices || !a->faces) return fail(NLOS_ERR_ARG, "nlos_render: empty mesh");
     if (a->num_samples <= 0) return fail(NLOS_ERR_ARG, "nlos_render: num_samples must be positive");
+    // (the fast path below does not pass through nlos_render's checks: a refine_scale or sigma_bin below 1 would divide by
+    // zero in the tap tables or size them negatively, an inverted window would render garbage)
+    if (int rcw = check_window_and_taps(a)) return rcw;
+    if (!a->transient) return fail(NLOS_ERR_ARG, "nlos_render: transient is NULL");
+    if (a->mode == NLOS_MODE_GRADIENT && (!a->data || !a->gradient))
+        return fail(NLOS_ERR_ARG, "nlos_render: gradient modes need data and a gradient output");
     DeviceGuard guard(c->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int La = a->L, Sb = a->n_sensors, nF = a->F, nV = a->V;
@@ -993,6 +1028,8 @@ static int render_product(nlos_ctx* c, const nlos_render_args* a, void* stream) 
     struct NoteScope { NoteScope(nlos::LaunchNote* n) { nlos::tl_note = n; } ~NoteScope() { nlos::tl_note = nullptr; } } note_scope(&note);
     std::memset(&c->path, 0, sizeof(c->path));
     c->path.workgroups = c->path.coarsened = c->path.big_lds = c->path.bvh_queries = -1;
+    c->path.rays_traced = c->path.samples_accepted = -1;
+    c->path_items_sources = 0;
     c->path_retry_workgroups = 0;
     mark(c, 0, st);
     static const bool lazy_enabled = [] { const char* e = std::getenv("NLOS_LAZY_TREE"); return !e || std::atoi(e) != 0; }();
@@ -1136,6 +1173,15 @@ int nlos_ctx_last_path(nlos_ctx* c, nlos_path_info* out, int count_workgroups) {
         if (v == 1) ++out->big_lds;
         else if (v == 0x200) ++out->bvh_queries;
         else if (v >= 0x100 && v < 0x200) ++out->coarsened;
+    }
+    if (c->path_items_sources > 0 && c->vis_items.p && c->path.backend == NLOS_PATH_GRID) {
+        // header word of every source's item masks (forward_grid.hip): [39:16] rays traced, [63:40] samples accepted
+        const int L = c->path_items_sources;
+        std::vector<unsigned long long> hd((size_t)L);
+        HIP_TRY(hipMemcpy2D(hd.data(), sizeof(unsigned long long), c->vis_items.p, sizeof(unsigned long long) * (size_t)c->vis_items_stride,
+                            sizeof(unsigned long long), (size_t)L, hipMemcpyDeviceToHost));
+        out->rays_traced = 0; out->samples_accepted = 0;
+        for (unsigned long long v : hd) { out->rays_traced += (int64_t)((v >> 16) & 0xffffffull); out->samples_accepted += (int64_t)(v >> 40); }
     }
     return NLOS_OK;
 }

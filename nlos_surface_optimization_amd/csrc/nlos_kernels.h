@@ -25,6 +25,21 @@ inline void note_hip(hipError_t e, const char* what) {
     if (e != hipSuccess && tl_note && tl_note->err == hipSuccess) { tl_note->err = e; tl_note->err_what = what; }
 }
 
+// Compute units of the current device (hipDeviceAttributeMultiprocessorCount): the persistent grids are sized from it, so
+// that a partitioned MI355X (CPX / DPX modes expose 32 / 128 CUs per device) gets as many workgroups as it can hold, not
+// the 256-CU chip's.  Queried once per device.
+inline int device_cu_count() {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cache[dev] <= 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cache[dev] = n;
+    }
+    return cache[dev];
+}
+
 // ------------------------------------------------------------------ BVH build
 struct BuildArgs {
     const float* vertices;   // [V,3]
@@ -101,7 +116,7 @@ struct ForwardArgs {
     uint32_t* vis;           // [L, vis_words, F] accepted-sample bitmasks (or null)
     int vis_words;
     // The same cache in the order pass 1 produces it (single-workgroup grid, confocal, spt <= 32): per source
-    // [0] = number of live faces, [1 + i] = the 64-bit accepted mask of 64-ray item i; ray r = li * spt + s of the
+    // [0] = header (bits 15:0 number of live faces, 39:16 rays traced, 63:40 samples accepted), [1 + i] = the 64-bit accepted mask of 64-ray item i; ray r = li * spt + s of the
     // bucketed live list `live` (which then stays valid until the next pass 1).  One 8-byte store per item instead
     // of a word per (face, 32 strata) plus the dark faces' zero words: 4.5 MB instead of 145 MB on the metric workload.
     unsigned long long* vis_items;   // [L, items_stride] or null

@@ -111,6 +111,8 @@ class TransientRenderer:
         if count and info.workgroups >= 0:
             d.update(workgroups=int(info.workgroups), coarsened=int(info.coarsened), big_lds=int(info.big_lds),
                      bvh_queries=int(info.bvh_queries))
+        if count and info.rays_traced >= 0:
+            d.update(rays_traced=int(info.rays_traced), samples_accepted=int(info.samples_accepted))
         return d
 
     def check(self):

@@ -57,7 +57,13 @@ class RcclDirect:
     ncclCommInitRank) and calls ncclAllReduce(sum, float64, in place) directly on `torch.cuda.current_stream()`.
     STATUS: exercised with world size 1 on the GPU (tests/test_gpu_dist.py) -- no multi-GPU node has been available to
     this build, so like every N > 1 path here it is unmeasured on hardware; ShardedRenderer uses it only on request
-    (all_reduce="rccl-direct")."""
+    (all_reduce="rccl-direct").
+    RULES OF USE: this is a SECOND communicator on the same GPUs as torch's process group.  Collectives of the two must
+    not be in flight at the same time (a rank that enters a torch collective while another sits in this all-reduce can
+    deadlock both): synchronise the render stream -- or at least finish every all_reduce_sum_ -- before calling into
+    torch.distributed (ShardedRenderer.gather_transient does), and issue the calls in the same order on every rank.
+    If ncclCommInitRank fails on one rank the others block in theirs: construct it right after the process group, where a
+    launcher timeout catches that.  close() (or the context manager) destroys the communicator."""
 
     NCCL_FLOAT64, NCCL_SUM = 8, 0
 
@@ -66,6 +72,11 @@ class RcclDirect:
             lib_path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         self._lib = ctypes.CDLL(lib_path)
         self._lib.ncclGetErrorString.restype = ctypes.c_char_p
+        self._lib.ncclGetErrorString.argtypes = [ctypes.c_int]
+        self._lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(_NcclUniqueId)]
+        self._lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        for fn in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclCommDestroy"):
+            getattr(self._lib, fn).restype = ctypes.c_int
         self._lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
         self._lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_void_p, ctypes.c_void_p]
@@ -104,6 +115,19 @@ class RcclDirect:
             self._lib.ncclCommDestroy(self._comm)
             self._comm = None
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 def all_reduce_gradient(gradient, group=None):
     """Sum the per-rank partial vertex gradients in place (no-op without a process group)."""
@@ -134,7 +158,41 @@ class ShardedRenderer:
         # "rccl-direct": a communicator of this process's own, collectives on the render stream (see RcclDirect)
         self.direct = RcclDirect(rank, world_size, renderer.device, group) if all_reduce == "rccl-direct" else None
         self.slice, self.offset, self.stride = shard_slice(n_sources, rank, world_size, partition)
-        self.lo, self.hi = shard_bounds(n_sources, rank, world_size)   # (contiguous partition; kept for callers that index by block)
+        self.n_local = len(range(*self.slice.indices(self.n_sources)))
+        self._bounds = shard_bounds(n_sources, rank, world_size) if partition == "contiguous" else None
+
+    # Block bounds exist for the contiguous partition only.  With the strided one a caller that still slices its rows as
+    # [sr.lo:sr.hi] would hand the kernels rows of OTHER sources -- same shapes, a silently wrong gradient -- so asking
+    # for them raises; local() is the one way to take a rank's rows.
+    @property
+    def lo(self):
+        if self._bounds is None:
+            raise AttributeError("ShardedRenderer.lo: the strided partition has no contiguous block; slice with local()")
+        return self._bounds[0]
+
+    @property
+    def hi(self):
+        if self._bounds is None:
+            raise AttributeError("ShardedRenderer.hi: the strided partition has no contiguous block; slice with local()")
+        return self._bounds[1]
+
+    def close(self):
+        """Destroys the rank's own RCCL communicator (all_reduce="rccl-direct"); a no-op otherwise."""
+        if self.direct is not None:
+            self.direct.close()
+            self.direct = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def _check_local(self, origin):
+        if origin.shape[0] != self.n_local:
+            raise ValueError("ShardedRenderer: %d local sources handed in, this rank owns %d of %d (%s partition): slice per-source "
+                             "tensors with local()" % (origin.shape[0], self.n_local, self.n_sources, self.partition))
 
     def _keys(self):
         kw = dict(source_offset=self.offset, total_sources=self.n_sources)
@@ -149,6 +207,7 @@ class ShardedRenderer:
         return part if self.stride == 1 else part.contiguous()
 
     def render_transient(self, origin, normal, *args, **kw):
+        self._check_local(origin)
         return self.renderer.render_transient(origin, normal, *args, **self._keys(), **kw)
 
     def render_gradient(self, origin, normal, *args, **kw):
@@ -156,6 +215,7 @@ class ShardedRenderer:
         globally reduced gradient, pathlengths).  A caller-supplied `gradient=` buffer is accumulated into as
         the renderer does (v2 semantics) -- AFTER the reduction, so that what it already holds (e.g. a
         regulariser gradient present on every rank) is not multiplied by the world size."""
+        self._check_local(origin)
         into = kw.pop("gradient", None)
         transient, gradient, path = self.renderer.render_gradient(origin, normal, *args, **self._keys(), **kw)
         if self.direct is not None:
@@ -171,6 +231,8 @@ class ShardedRenderer:
         """Optional: assemble the full [L, T] transient on every rank (host asks for it rarely)."""
         if self.world_size == 1:
             return local_rows
+        if self.direct is not None:     # nothing of the process's own communicator in flight while torch's collective runs
+            torch.cuda.current_stream(local_rows.device).synchronize()
         slices = [shard_slice(self.n_sources, r, self.world_size, self.partition)[0] for r in range(self.world_size)]
         counts = [len(range(*sl.indices(self.n_sources))) for sl in slices]
         pad = torch.zeros((max(counts), local_rows.shape[1]), dtype=local_rows.dtype, device=local_rows.device)

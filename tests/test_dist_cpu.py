@@ -84,6 +84,19 @@ def _worker(rank, world, port, out_dir, partition="contiguous"):
         else:   # sources 0, 2, 4, 6 | 1, 3, 5
             assert (sr.offset, sr.stride, sr.local(origin).shape[0]) == ((0, 2, 4) if rank == 0 else (1, 2, 3))
             assert sr.local(origin).is_contiguous() and torch.equal(sr.local(origin), origin[rank::2])
+            # (round-4 advice) no block bounds for a strided shard: a stale [sr.lo:sr.hi] must fail, not mis-slice
+            for name in ("lo", "hi"):
+                try:
+                    getattr(sr, name)
+                    raise SystemExit("ShardedRenderer.%s of a strided shard did not raise" % name)
+                except AttributeError:
+                    pass
+        # rows of the wrong shard (shapes that do not match this rank's share) are refused before anything is rendered
+        try:
+            sr.render_transient(origin, normal, v, f, ns, lb, ub, res)
+            raise SystemExit("ShardedRenderer accepted the global rows as local ones")
+        except ValueError:
+            pass
         t_loc, grad, _ = sr.render_gradient(sr.local(origin), sr.local(normal), v, f, ns, lb, ub, res,
                                             data=sr.local(data), weight=sr.local(weight))
         full = sr.gather_transient(t_loc)

@@ -103,9 +103,19 @@ def test_last_path_reports_backend_reason_and_workgroup_outcomes(bunny, mannequi
     assert p["backend"] == "grid" and p["reason"] == "" and p["tiles"] == 1 and p["chunks"] == 1 and p["rows_in_lds"]
     assert p["gradient_kernel"] == "none"
     assert p["workgroups"] == 9 and p["big_lds"] == 0 and p["bvh_queries"] == 0
+    assert "rays_traced" not in p        # (a forward-only render keeps no item masks: nothing to count from)
+    # what pass 1 did with the L * F * spt surface samples (round 5): the item-mask headers carry, per source, the rays that
+    # went through the occlusion query and the samples that were binned; the second equals the set bits of the cache
+    F = tf.shape[0]
+    spt = 1 + (ns - 1) // F
+    r.render_transient(to, tn, tv, tf, ns, LB, UB, RES, keep_visibility=True)
+    p = r.last_path(count=True)
+    vis, _ = r.debug_visibility(9, spt, F)
+    accepted = int(sum(bin(int(w)).count("1") for w in vis.ravel()))
+    assert p["samples_accepted"] == accepted and 0 < accepted <= p["rays_traced"] < 9 * F * spt
     r.render_transient(to, tn, tv, tf, ns, LB, UB, RES, force_bvh=True)
-    p = r.last_path()
-    assert p["backend"] == "bvh" and p["reason"] == "force_bvh"
+    p = r.last_path(count=True)
+    assert p["backend"] == "bvh" and p["reason"] == "force_bvh" and "rays_traced" not in p
     # a wall point inside the scene's depth range: that workgroup traces through the in-kernel BVH query
     o2 = o.copy()
     o2[4, 2] = 0.45

@@ -168,3 +168,34 @@ def test_product_of_a_grid_of_wall_points_full_rows(orc, bunny, renderer):
                                          shared_samples=1)
     assert rel_l2(t[li, sj], t_ref) < 1e-12
     assert rel_l2(t.transpose(1, 0, 2), t) < 1e-5
+
+
+@pytest.mark.parametrize("bad", [dict(refine_scale=0), dict(sigma_bin=0), dict(refine_scale=-3), dict(sigma_bin=-1),
+                                 dict(refine_scale=600), dict(lower_bound=1.625, upper_bound=0.625),
+                                 dict(resolution=-2.0 ** -9), dict(transient=None), dict(data=None)])
+def test_product_gradient_rejects_what_nlos_render_rejects(bunny, renderer, bad):
+    """The record + combine fast path does not go through nlos_render's argument checks (round-4 advice): a refine_scale
+    or sigma_bin below 1 (division by zero in the tap tables, a negative table size that threw across the C boundary), an
+    over-long temporal kernel, an inverted window or a missing output must come back as NLOS_ERR_ARG from the product
+    entry as well -- straight through the C ABI, so that nothing on the Python side can catch it first."""
+    import ctypes
+    import torch
+    from nlos_surface_optimization_amd import _lib
+    v, f = bunny
+    la, lan = _wall([[0.1, 0.0, 0], [-0.2, 0.1, 0]])
+    sb, sbn = _wall([[0.1, 0.0, 0], [0.2, 0.2, 0]])
+    tl, tln, ts, tsn, tv, tf = _dev(la, lan, sb, sbn, v, f)
+    a = renderer._args(_lib.MODE_GRADIENT, tl, tln, tv, tf, 3 * f.shape[0], LB, UB, RES, 10, 1)
+    trans = torch.zeros((2, 2, T), dtype=torch.float64, device="cuda:0")
+    data = torch.zeros((2, 2, T), dtype=torch.float64, device="cuda:0")
+    grad = torch.zeros((v.shape[0], 3), dtype=torch.float64, device="cuda:0")
+    a.sensor, a.sensor_normal, a.n_sensors = ts.data_ptr(), tsn.data_ptr(), 2
+    a.transient, a.data, a.gradient, a.testing_flag = trans.data_ptr(), data.data_ptr(), grad.data_ptr(), 1
+    for k, val in bad.items():
+        setattr(a, k, val)
+    rc = renderer._lib.nlos_render(renderer._h, ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == -1, (bad, rc)         # NLOS_ERR_ARG
+    assert b"nlos_render" in renderer._lib.nlos_last_error()
+    # the context is still usable, and the same arguments without the defect render
+    t, _, _ = renderer.render_product(tl, tln, ts, tsn, tv, tf, 3 * f.shape[0], LB, UB, RES)
+    assert float(t.sum()) > 0

@@ -18,7 +18,9 @@ import re
 import sys
 
 FULL, HALF, QUARTER, SALU = 2.3, 4.1, 8.1, 4.15
-N_SIMD = 1024
+# four SIMDs per compute unit; the CU count of the profiled device comes from tools/round_summary.py / profile_round.sh
+# (NLOS_COMPUTE_UNITS = torch's multi_processor_count there), 256 = an unpartitioned MI355X otherwise
+N_SIMD = 4 * int(os.environ.get("NLOS_COMPUTE_UNITS", "256"))
 # engine clock: measured on the forward kernel itself (tools/build_stamps.sh -> clock.json -> NLOS_CLOCK_GHZ, set by
 # tools/round_summary.py) when available, else the 2.4 GHz peak (then `busy` is a lower bound)
 CLOCK = float(os.environ.get("NLOS_CLOCK_GHZ", "2.4")) * 1e9
@@ -79,9 +81,9 @@ def main():
                     "int32 + unclassified (2.3 ... 4.1)": mixed},
         "mixed_full_rate_fraction": frac_full, "mixed_fraction_basis": "static ISA histogram" if share is not None else "50/50",
         "basis": ("issue costs: profiles/r03_issue_rates.json (tools/issue_rate.hip, >= 2 waves per SIMD); counters: SQ_INSTS_VALU* "
-                  "(tools/pmc_classes.sh, separate --pmc passes); 1024 SIMDs, engine clock %.3f GHz (%s); the scalar unit serves one "
+                  "(tools/pmc_classes.sh, separate --pmc passes); %d SIMDs, engine clock %.3f GHz (%s); the scalar unit serves one "
                   "SIMD every 4.15 cycles and overlaps with vector issue of other waves"
-                  % (CLOCK / 1e9, "measured on the forward kernel: s_memtime / s_memrealtime, tools/build_stamps.sh"
+                  % (N_SIMD, CLOCK / 1e9, "measured on the forward kernel: s_memtime / s_memrealtime, tools/build_stamps.sh"
                      if "NLOS_CLOCK_GHZ" in os.environ else "peak: a lower bound on busy")),
     }
     print(json.dumps(out, indent=1))

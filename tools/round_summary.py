@@ -57,6 +57,12 @@ def model(name, ms):
     cmd = [sys.executable, os.path.join(here, "issue_model.py"), os.path.join(here, "..", "profiles", "r03_issue_rates.json"),
            os.path.join(root, "pmc_summary_all.json"), name, "%.6f" % ms] + ([isa] if os.path.exists(isa) else [])
     env = dict(os.environ)
+    try:      # the CU count of the profiled device (an MI355X partition exposes fewer than 256)
+        import torch
+        if torch.cuda.is_available():
+            env.setdefault("NLOS_COMPUTE_UNITS", str(torch.cuda.get_device_properties(0).multi_processor_count))
+    except Exception:
+        pass
     if clock and clock.get("clock_ghz"):
         env["NLOS_CLOCK_GHZ"] = "%.5f" % clock["clock_ghz"]
     return json.loads(subprocess.check_output(cmd, env=env))
