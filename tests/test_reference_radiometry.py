@@ -111,3 +111,35 @@ def test_vertex_gradient_matches_finite_differences_of_the_reference_forward(orc
                 worst = max(worst, abs(fd.mean() - analytic) / abs(analytic))
                 assert sem / abs(analytic) < 0.03                   # the stated error of the pin: <= 3 % per functional
     assert worst < 0.03
+
+
+def test_one_call_over_all_sources_carries_the_reference_one_over_L(orc, fx):
+    """The same functionals with all sources in ONE call: the driver averages the per-source gradients,
+    gradient = (1 / L) sum_l g_l (smoothed_transient/transient_and_gradient.cpp:561-565), so the contraction with a motion
+    must equal the MEAN over the sources of the reference's finite differences.  (The test above renders one source per
+    call, L = 1, and cannot see a wrong normalisation.)"""
+    name = "plane"
+    v, f, src, nrm, nbin, z, zsplit = _scene(fx, name)
+    res, nb, delta = float(fx["res"]), int(fx["batches"]), float(fx["delta"])
+    motions, moved = fx[name + "_motions"], fx[name + "_moved"].astype(np.float64)
+    L = src.shape[0]
+    assert L >= 2
+    ns = f.shape[0] * 1000000
+    tr, _ = orc.render_transient(src, nrm, v, f, ns, 0.0, nbin * res, res / FINE, seed=3, accel=0)
+    _, g, _ = orc.render_gradient(src, nrm, v, f, ns, 0.0, nbin * res, res / FINE, tr - 0.5, np.ones_like(tr), refine=10,
+                                  sigma_bin=1, testing_flag=1, seed=3, accel=0)
+    checked = 0
+    for q in range(motions.shape[0]):
+        dz = delta if q % 4 == 2 else 0.0
+        fd = np.stack([((moved[q, 0, :, i] * _cos2(nbin, 1, res, z[0] + dz, z[1] + dz, zsplit)).sum(axis=1) -
+                        (moved[q, 1, :, i] * _cos2(nbin, 1, res, z[0] - dz, z[1] - dz, zsplit)).sum(axis=1)) / (2 * delta)
+                       for i in range(L)])                              # [source, batch]
+        mean_fd = fd.mean(axis=1).mean()                                # (1 / L) sum_l dPhi_l / dq
+        sem = np.sqrt(((fd.std(axis=1, ddof=1) / np.sqrt(nb)) ** 2).sum()) / L
+        analytic = float((g * motions[q]).sum())
+        assert abs(mean_fd - analytic) <= 4 * sem + 0.015 * abs(analytic), ("xyzs"[q % 4], mean_fd, sem, analytic)
+        if abs(analytic) > 1.0:
+            checked += 1
+            # a missing 1 / L would be off by a factor L >= 2, a 1 / (L - 1) or 1 / (L + 1) by >= 20 %: far outside 4 sigma + 1.5 %
+            assert abs(L * mean_fd - analytic) > 10 * (4 * sem + 0.015 * abs(analytic))
+    assert checked >= 2
