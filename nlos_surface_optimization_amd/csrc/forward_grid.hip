@@ -1265,6 +1265,13 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     if (tid == 0 && a.dbg) {   // the shader clock this kernel really ran at: sum of s_memtime ticks / sum of s_memrealtime ticks (100 MHz)
         atomicAdd((unsigned long long*)&a.dbg[24], (unsigned long long)(clock64() - c_start));
         atomicAdd((unsigned long long*)&a.dbg[25], (unsigned long long)(wall_clock64() - w_start));
+        // this workgroup's lifetime in shader-clock cycles, into the first bytes of its own (now dead) coverage scratch:
+        // the per-source spread behind strong scaling (one resident round of workgroups lasts as long as its heaviest source)
+        if (!TILED && (F & 1) == 0) {
+            const unsigned long long dt = (unsigned long long)(clock64() - c_start);
+            uint32_t* cw = reinterpret_cast<uint32_t*>(g_cov);
+            cw[0] = (uint32_t)dt; cw[1] = (uint32_t)(dt >> 32);
+        }
     }
 #endif
     // diagnostics (nlos_ctx_debug_read what = 2): the coarsened resolution this workgroup ended up with; the

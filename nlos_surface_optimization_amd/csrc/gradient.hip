@@ -59,7 +59,10 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
     double* s_delta = s_diff + T;           // [K]
     double* s_p0 = s_delta + K;             // [K+1]
     double* s_p1 = s_p0 + K + 1;            // [K+1]
-    double* s_grad = s_p1 + K + 1;          // [3V] when lds_grad
+    // per-bin tap weights (TapTables::wt; vertex gradient with Gaussian taps) when the launcher made room for them
+    const int n_wt = (MODE == 0 && a.tap_wt && a.wt_in_lds) ? 2 * (a.refine + 1) * a.tap_nb : 0;
+    double* s_wt = s_p1 + K + 1;            // [n_wt]
+    double* s_grad = s_wt + n_wt;           // [3V] when lds_grad
     unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(s_grad + (((MODE == 0 || MODE == 4) && a.lds_grad) ? 3 * V : 0));
     uint32_t* s_base = reinterpret_cast<uint32_t*>(s_mask + nblocks);              // [nblocks+1]
     uint16_t* s_live = reinterpret_cast<uint16_t*>(s_base + ((nblocks + 2) & ~1));   // [F] sorted face slots (compact only)
@@ -76,11 +79,13 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
         // scalar gradients (modes 1, 2) group their taps over the double weights
         for (int i = threadIdx.x; i <= K; i += blockDim.x) { s_p0[i] = (MODE == 1 || MODE == 2) ? a.tap_pw[i] : a.tap_p0[i]; s_p1[i] = a.tap_p1[i]; }
     }
+    for (int i = threadIdx.x; i < n_wt; i += blockDim.x) s_wt[i] = a.tap_wt[i];
     if ((MODE == 0 || MODE == 4) && a.lds_grad)
         for (int i = threadIdx.x; i < 3 * V; i += blockDim.x) s_grad[i] = 0.0;
     double scalar_acc = 0.0;
     TapTables tt;
     tt.delta = s_delta; tt.p0 = s_p0; tt.p1 = s_p1; tt.K = K; tt.two_rs = a.two_rs; tt.r_over_res = a.r_over_res; tt.refine = a.refine;
+    tt.wt = n_wt ? s_wt : nullptr; tt.nb = a.tap_nb;
 
     for (int l = blockIdx.x; l < a.src.L; l += gridDim.x) {
         __syncthreads();                    // previous source done with s_diff
@@ -391,6 +396,7 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
     }
     TapTables tt;
     tt.delta = s_delta; tt.p0 = s_p0; tt.p1 = s_p1; tt.K = K; tt.two_rs = a.two_rs; tt.r_over_res = a.r_over_res; tt.refine = a.refine;
+    tt.wt = nullptr; tt.nb = 0;             // (the face-major kernel keeps the boundary arithmetic: its LDS is full)
 
     for (int lb0 = l0; lb0 < l1; lb0 += kFmBatch) {
         const int nb = min(kFmBatch, l1 - lb0);
@@ -621,6 +627,12 @@ void launch_gradient(const GradientArgs& a_in, hipStream_t stream) {
     GradientArgs a = a_in;
     const size_t nblk = ((size_t)a.sc.F + 63) / 64;
     size_t lds = 8 + ((size_t)a.sp.nbins + 3 * (size_t)a.K + 2) * sizeof(double) + nblk * 8 + ((nblk + 2) & ~(size_t)1) * 4;
+    // per-bin tap weights beside the prefix sums (TapTables::wt) while the table is small (refine 10, sigma_bin 1: 880 B)
+    a.wt_in_lds = 0;
+    if (a.mode == 0 && a.tap_wt && a.tap_nb > 0 && a.K > 1) {
+        const size_t wt = sizeof(double) * 2 * (size_t)(a.refine + 1) * (size_t)a.tap_nb;
+        if (wt <= 4096) { a.wt_in_lds = 1; lds += wt; }
+    }
     // compacted list of the faces with accepted samples (u16): skipped for meshes it cannot index / hold
     a.compact = (a.sc.F <= 65535 && lds + 2 * (size_t)a.sc.F + 16 <= 64 * 1024) ? 1 : 0;
     if (a.compact) lds += (2 * (size_t)a.sc.F + 15) & ~(size_t)15;

@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -194,6 +195,22 @@ void host_taps(int refine, int sigma_bin, float res, std::vector<double>& t) {
         t[2 * K + i] = (double)(float)(dl / sigma_square * 2);
     }
     host_prefix(t, K);
+    // the per-bin weights of the grouped-tap loop, by the tap ic at which the first bin boundary falls (render_common.h,
+    // TapTables::wt): bins k = 0 .. nb - 1 hold the taps [min(K, ic + (k - 1) refine), min(K, ic + k refine)), the last one up to K
+    const int nb = 4 * sigma_bin + 1;
+    const size_t base = t.size();
+    t.resize(base + 2 * (size_t)(refine + 1) * nb, 0.0);
+    const double* P0 = t.data() + 3 * (size_t)K;
+    const double* P1 = t.data() + 4 * (size_t)K + 1;
+    for (int ic = 0; ic <= refine; ++ic) {
+        int prev = 0;
+        for (int k = 0; k < nb; ++k) {
+            const int ie = k < nb - 1 ? std::max(prev, std::min(K, ic + k * refine)) : K;
+            t[base + 2 * ((size_t)ic * nb + k)] = P0[ie] - P0[prev];
+            t[base + 2 * ((size_t)ic * nb + k) + 1] = P1[ie] - P1[prev];
+            prev = ie;
+        }
+    }
 }
 
 // single unit tap (v1 gradient: delta 0, weight 1)
@@ -815,6 +832,18 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
                 }
             }
         }
+        if (!fa.tile_list && fa.cov && (nF & 1) == 0 && L > 0 && note.backend == NLOS_PATH_GRID) {
+            // per-source lifetimes of the grid kernel's workgroups (cycles): the spread that bounds strong scaling
+            std::vector<unsigned long long> cyc((size_t)L);
+            if (hipMemcpy2D(cyc.data(), 8, fa.cov, sizeof(uint16_t) * (size_t)nF, 8, (size_t)L, hipMemcpyDeviceToHost) == hipSuccess) {
+                std::sort(cyc.begin(), cyc.end());
+                double sum = 0; for (auto v : cyc) sum += (double)v;
+                const double mean = sum / L;
+                auto pct = [&](double p) { return (double)cyc[(size_t)std::min<double>(L - 1, p * (L - 1))]; };
+                std::fprintf(stderr, "[fwd per-source cycles] min %.0f p50 %.0f mean %.0f p90 %.0f p99 %.0f max %.0f | max/mean %.3f p99/mean %.3f over %d sources\n",
+                             (double)cyc.front(), pct(0.5), mean, pct(0.9), pct(0.99), (double)cyc.back(), cyc.back() / mean, pct(0.99) / mean, L);
+            }
+        }
         if (fa.tile_list)
             std::fprintf(stderr, "[fwd tiles] %d x %d tiles, capacity %d: %lld overflowing tiles, largest subset %lld | entry overflow: %lld workgroups, most entries %lld\n",
                          fa.tiles_x, fa.tiles_y, fa.tile_cap, h[22], h[23], h[20], h[21]);
@@ -914,12 +943,17 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         ga.diff_scratch = c->diff.as<double>();
         ga.tap_w = c->taps.as<double>(); ga.tap_delta = ga.tap_w + K; ga.tap_g = ga.tap_w + 2 * K;
         ga.tap_p0 = ga.tap_w + 3 * K; ga.tap_p1 = ga.tap_w + 4 * K + 1; ga.tap_pw = ga.tap_w + 5 * K + 2;
+        ga.tap_wt = nullptr; ga.tap_nb = 0;
         ga.K = K;
         const bool v1 = mode == NLOS_MODE_GRADIENT_V1;
         ga.two_rs = v1 ? 0 : 2 * a->refine_scale * a->sigma_bin;
         ga.r_over_res = v1 ? 1.0 : (double)a->refine_scale / (double)res;
         ga.refine = v1 ? 1 : a->refine_scale;
         ga.v1_style = mode == NLOS_MODE_GRADIENT_V1 ? 1 : 0;
+        if (mode == NLOS_MODE_GRADIENT && !jitter) {       // per-bin weights of the Gaussian taps (host_taps)
+            ga.tap_wt = ga.tap_w + 6 * (size_t)K + 3;
+            ga.tap_nb = 4 * a->sigma_bin + 1;
+        }
         ga.vertex_num = a->vertex_num;
         ga.diff = diff_ptr;
         switch (mode) {
@@ -1122,10 +1156,13 @@ static int render_product(nlos_ctx* c, const nlos_render_args* a, void* stream) 
         ga.vis = c->vis.as<uint32_t>(); ga.vis_words = 1; ga.vis_scratch = c->vis.as<uint32_t>();
         ga.tap_w = c->taps.as<double>(); ga.tap_delta = ga.tap_w + K; ga.tap_g = ga.tap_w + 2 * K;
         ga.tap_p0 = ga.tap_w + 3 * K; ga.tap_p1 = ga.tap_w + 4 * K + 1; ga.tap_pw = ga.tap_w + 5 * K + 2;
+        ga.tap_wt = nullptr; ga.tap_nb = 0;
         ga.K = K;
         ga.two_rs = 2 * a->refine_scale * a->sigma_bin;
         ga.r_over_res = (double)a->refine_scale / (double)res;
         ga.refine = a->refine_scale;
+        ga.tap_wt = ga.tap_w + 6 * (size_t)K + 3;
+        ga.tap_nb = 4 * a->sigma_bin + 1;
         ga.diff = c->diff.as<double>();
         ga.mode = 0;
         ga.normal_term = a->normal_term < 0 ? 0 : (a->normal_term ? 1 : 0);      // (face normals: the reference rule gives 0)

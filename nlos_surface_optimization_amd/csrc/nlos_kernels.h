@@ -231,6 +231,9 @@ struct GradientArgs {
     const double* tap_p0;    // [K+1] prefix sums of (double)(float)w
     const double* tap_p1;    // [K+1] prefix sums of g * (double)(float)w
     const double* tap_pw;    // [K+1] prefix sums of w (double): scalar gradients
+    const double* tap_wt;    // [(refine + 1) * tap_nb * 2] per-bin weights by first-boundary tap (render_common.h, TapTables::wt) or null
+    int tap_nb;              // 4 sigma_bin + 1
+    int wt_in_lds;           // set by launch_gradient: k_gradient stages tap_wt in LDS
     int K;
     int two_rs;              // 2*refine*sigma_bin (index of the centre tap)
     double r_over_res;       // refine / resolution

@@ -343,6 +343,13 @@ struct TapTables {
     const double* p1;      // [K+1]
     int K, two_rs, refine;
     double r_over_res;     // refine / res
+    // Round 5: the bin weights themselves.  With the first boundary at tap ic (1 <= ic <= refine) the taps fall into
+    // nb = 4 sigma_bin + 1 bins whose boundaries are ic, ic + refine, ...: the per-bin differences of the prefix sums depend on
+    // ic alone, so the host tabulates them -- wt[(ic * nb + k) * 2 + {0, 1}] = P{0,1}[end_k] - P{0,1}[start_k], the very
+    // subtractions the loop below performs (same doubles, same bits) -- and a sample pays two loads and two fused
+    // multiply-adds per bin instead of the boundary arithmetic (20 of the ~300 VALU instructions of a sample, five times).
+    const double* wt;      // or null
+    int nb;
 };
 
 // s_m2diff: the residual row as (double)(float)(-2 d)
@@ -353,7 +360,6 @@ __device__ __forceinline__ void grouped_taps(const TapTables& tt, const double* 
     s1 = 0.0;
     const int K = tt.K;
     const int b_first = tap_bin(twoh, tt.delta[0], lbd, resd, inv_res);
-    const int b_last = tap_bin(twoh, tt.delta[K - 1], lbd, resd, inv_res);
     // first tap whose bin exceeds b: delta_i >= (b+1)*res + lb - 2h, i.e. a boundary y (in continuous tap
     // index, minus two_rs); consecutive boundaries are exactly `refine` taps apart
     const double thr0 = ((double)(b_first + 1) * resd + lbd) - twoh;
@@ -362,7 +368,36 @@ __device__ __forceinline__ void grouped_taps(const TapTables& tt, const double* 
     // delta_i carries the fp32 rounding of (i - two_rs) * res / refine (<= ~1e-6 taps): the closed form is the
     // reference's per-tap assignment unless the boundary is that close to a tap.  All boundaries of a sample
     // share the fractional part of y0 (to ~1e-13), so one test decides for the whole sample.
-    if (b_first == b_last || (yc0 - y0 >= 1e-4 && y0 - (yc0 - 1.0) >= 1e-4)) {
+    const bool clear = yc0 - y0 >= 1e-4 && y0 - (yc0 - 1.0) >= 1e-4;
+    if (tt.wt && clear) {
+        // tabulated bin weights: with the first boundary at tap ic in [1, refine] the K = 4 refine sigma + 1 taps meet
+        // 4 sigma boundaries (ic + k refine <= K - 1 for k <= 4 sigma - 1), i.e. nb = 4 sigma + 1 bins from b_first on --
+        // the last tap's bin needs no evaluation of its own
+        const int ic = (int)yc0 + tt.two_rs;
+        if (ic >= 1 && ic <= tt.refine) {
+            const double* w = tt.wt + 2 * (size_t)(ic * tt.nb);
+            if (tt.nb == 5 && b_first >= 0 && b_first + 5 <= T) {          // (sigma_bin = 1, the window inside the row: no checks)
+                const double* d = s_m2diff + b_first;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    s0 = fma(d[k], w[2 * k], s0);
+                    s1 = fma(d[k], w[2 * k + 1], s1);
+                }
+                return;
+            }
+            for (int k = 0; k < tt.nb; ++k) {
+                const int b = b_first + k;
+                if (b >= 0 && b < T) {
+                    const double dd = s_m2diff[b];
+                    s0 = fma(dd, w[2 * k], s0);
+                    s1 = fma(dd, w[2 * k + 1], s1);
+                }
+            }
+            return;
+        }
+    }
+    const int b_last = tap_bin(twoh, tt.delta[K - 1], lbd, resd, inv_res);
+    if (b_first == b_last || clear) {
         int ic = (int)yc0 + tt.two_rs;
         int i_start = 0;
         double q0 = tt.p0[0], q1 = tt.p1[0];
