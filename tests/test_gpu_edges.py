@@ -152,3 +152,53 @@ def test_rerun_is_deterministic_up_to_summation_order_and_seed_matters(bunny):
         _lib.lib().nlos_set_default_seed(0)
     assert np.abs(a - c).max() > 1e-6 * a.max()                       # another stream of samples
     assert abs(a.sum() - c.sum()) < 0.05 * a.sum()                    # same estimator
+
+
+@pytest.mark.parametrize("case", ["small_lean", "large_lean", "small_with_gradient", "large_with_gradient", "frame_guard",
+                                  "window_guard_small", "window_guard_large"])
+def test_scenes_at_the_edges_of_the_lean_arithmetic_range(bunny, orc, case):
+    """Round 5: the grid trace evaluates sqrt / reciprocal / division in their bare refinement forms (csrc/nlos_device.h),
+    which are the IEEE results between 2^-60 and 2^60 only.  The range is guaranteed per source (source_frame: every vertex
+    between 2^-29 and 2^28 from the wall point, else the in-kernel BVH query with the IEEE forms) and per launch
+    (lean_params_ok: resolution in [2^-30, 2^30], bounds within 2^29, else the BVH back-end, reason 7).  The scene scaled to
+    both ends of the range, and just past each guard, must give the oracle's rows (identical decisions: fp64 summation order
+    only) -- the oracle computes in IEEE arithmetic at any scale."""
+    import torch
+    from nlos_surface_optimization_amd import device as nd
+    v, f = bunny
+    o, n = grid_sources(3, 0.2)
+    lb, ub, res = LB, UB, RES
+    s = {"small_lean": 2.0 ** -20, "large_lean": 2.0 ** 28, "small_with_gradient": 2.0 ** -16, "large_with_gradient": 2.0 ** 16,
+         "frame_guard": 2.0 ** -28, "window_guard_small": 2.0 ** -30, "window_guard_large": 2.0 ** 29}[case]
+    vs, os_ = (v.astype(np.float64) * s).astype(np.float32), (o.astype(np.float64) * s).astype(np.float32)
+    lb, ub, res = np.float32(lb * s), np.float32(ub * s), np.float32(res * s)
+    if case == "frame_guard":
+        # resolution inside the launch guard (2^-9 2^-20 would be 2^-37: stretch the window instead), depth 0.38 2^-28 < 2^-29
+        res = np.float32(2.0 ** -29)
+        lb, ub = np.float32(0.0), np.float32(512 * 2.0 ** -29)
+    ns = 3 * f.shape[0]
+    t_ref, _ = orc.render_transient(os_, n, vs, f, ns, float(lb), float(ub), float(res), accel=1)
+    assert t_ref.sum() > 0 and (t_ref.sum(axis=1) > 0).all()
+    dev = torch.device("cuda", 0)
+    r = nd.TransientRenderer(dev, seed=0)
+    tv, tf, to, tn = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (vs, f, os_, n))
+    tr, _ = r.render_transient(to, tn, tv, tf, ns, float(lb), float(ub), float(res))
+    p = r.last_path(count=True)
+    if case in ("small_lean", "large_lean", "small_with_gradient", "large_with_gradient"):
+        assert p["backend"] == "grid" and p["bvh_queries"] == 0
+    elif case == "frame_guard":
+        assert p["backend"] == "grid" and p["bvh_queries"] == 9          # every source outside the per-source range
+    else:
+        assert p["backend"] == "bvh" and p["reason"] == "time window outside the grid trace's arithmetic range"
+    assert rel_l2(tr.cpu().numpy(), t_ref) <= 1e-12, (case, p)
+    if not case.endswith("with_gradient"):
+        # the gradient's own fp32 intermediates -- the reference's: t2 = (n I + gn) / (2 area) ~ scale^-6 -- leave the float
+        # range beyond scale 2^+-18, in the oracle as in the kernels: rows only there
+        r.close()
+        return
+    d, w = t_ref * 0.7, np.ones_like(t_ref)
+    _, g_ref, _ = orc.render_gradient(os_, n, vs, f, ns, float(lb), float(ub), float(res), d, w, accel=1)
+    td, tw = torch.from_numpy(d).to(dev), torch.from_numpy(w).to(dev)
+    _, g, _ = r.render_gradient(to, tn, tv, tf, ns, float(lb), float(ub), float(res), data=td, weight=tw)
+    assert rel_l2(g.cpu().numpy(), g_ref) <= 1e-4, case
+    r.close()
