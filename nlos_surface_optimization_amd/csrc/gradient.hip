@@ -38,6 +38,44 @@ __global__ __launch_bounds__(256) void k_items_to_words(const unsigned long long
     for (int li = threadIdx.x; li < n_live; li += blockDim.x) w[live[(size_t)l * F + li]] = item_bits(it, li, spt);
 }
 
+// Per accepted sample the nine sums of a face grow by (t1 b_q + t2 x e_q) s0 + di b_q s1, q = 0, 1, 2.  The edges e_q belong
+// to the FACE, so sum_s (t2_s x e_q) s0_s = (sum_s t2_s s0_s) x e_q: the sample adds b_q P to the nine sums, P = t1 s0 + di s1,
+// and t2 s0 to three more (all in fp64), and the three cross products are taken once per face -- 30 instead of 36
+// half-rate operations per sample, and none of the three fp32 cross products, nine edge subtractions and eighteen A1 / A2
+// operations the per-sample form needed (round 5: pass 2 0.383 -> see HISTORY.md R5).
+struct FaceSums {
+    double p[9];     // sum b_q P[c]
+    double x[3];     // sum t2[c] s0
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) p[q] = 0.0;
+        x[0] = x[1] = x[2] = 0.0;
+    }
+    __device__ __forceinline__ void add(V3 t1, V3 t2, V3 di, float b0, float b1, float b2, double s0, double s1) {
+        const double px = fma((double)t1.x, s0, (double)di.x * s1), py = fma((double)t1.y, s0, (double)di.y * s1),
+                     pz = fma((double)t1.z, s0, (double)di.z * s1);
+        x[0] = fma((double)t2.x, s0, x[0]); x[1] = fma((double)t2.y, s0, x[1]); x[2] = fma((double)t2.z, s0, x[2]);
+        const double bq[3] = {(double)b0, (double)b1, (double)b2};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            p[3 * q + 0] = fma(bq[q], px, p[3 * q + 0]);
+            p[3 * q + 1] = fma(bq[q], py, p[3 * q + 1]);
+            p[3 * q + 2] = fma(bq[q], pz, p[3 * q + 2]);
+        }
+    }
+    // the nine sums: p + x cross e_q, e_0 = p2 - p1, e_1 = p0 - p2, e_2 = p1 - p0 (fp32 differences, as the per-sample form took them)
+    __device__ __forceinline__ void finish(const Face& f, double* out9) const {
+        const V3 e[3] = {f.p2 - f.p1, f.p0 - f.p2, f.p1 - f.p0};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const double ex = (double)e[q].x, ey = (double)e[q].y, ez = (double)e[q].z;
+            out9[3 * q + 0] = p[3 * q + 0] + fma(x[1], ez, -(x[2] * ey));
+            out9[3 * q + 1] = p[3 * q + 1] + fma(x[2], ex, -(x[0] * ez));
+            out9[3 * q + 2] = p[3 * q + 2] + fma(x[0], ey, -(x[1] * ex));
+        }
+    }
+};
+
 #ifndef NLOS_GRAD_NT
 #define NLOS_GRAD_NT 512
 #define NLOS_GRAD_WPS 4
@@ -178,9 +216,8 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
             load_face_tri<FEAT | FEAT_VN>(a.sc, j, f, tr);    // vertices, ids, and the per-face constants the scene build evaluated
             if (MODE == 3 && f.i0 != a.vertex_num && f.i1 != a.vertex_num && f.i2 != a.vertex_num) continue;
             const uint64_t kbase = (lg * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
-            double acc[9];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) acc[q] = 0.0;
+            FaceSums fs;
+            fs.clear();
             double sacc = 0.0;
 
             for (int wi = 0; wi < n_words; ++wi) {
@@ -214,20 +251,10 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                             continue;
                         GVec gv;
                         grad_vectors_nc<FEAT>(f, gc, on, onb, a.normal_term, a.sp.ggx_alpha, gv);
-                        const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
-                        const V3 ce[3] = {cross(gv.t2, e0), cross(gv.t2, e1), cross(gv.t2, e2)};
                         double s0, s1;
                         grouped_taps(tt, s_diff, T, (double)(gc.d1 + gc.d2), lbd, resd, inv_res, s0, s1);
                         const V3 di = ((gc.dirA + gc.dirB) * 0.5f) * gv.inten_f;
-                        const float bw[3] = {gc.u, gc.v, gc.w};
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) {
-                            V3 A1 = grad_axpy(gv.t1, bw[q], ce[q]);
-                            V3 A2 = di * bw[q];
-                            acc[3 * q + 0] = fma((double)A1.x, s0, fma((double)A2.x, s1, acc[3 * q + 0]));
-                            acc[3 * q + 1] = fma((double)A1.y, s0, fma((double)A2.y, s1, acc[3 * q + 1]));
-                            acc[3 * q + 2] = fma((double)A1.z, s0, fma((double)A2.z, s1, acc[3 * q + 2]));
-                        }
+                        fs.add(gv.t1, gv.t2, di, gc.u, gc.v, gc.w, s0, s1);
                         continue;
                     }
                     Geo g;
@@ -257,10 +284,10 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                     }
                     GVec gv;
                     grad_vectors<FEAT>(f, g, on, a.normal_term, a.v1_style, a.sp.ggx_alpha, gv);
-                    const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
-                    const V3 ce0 = cross(gv.t2, e0), ce1 = cross(gv.t2, e1), ce2 = cross(gv.t2, e2);
                     if (MODE == 3) {
                         // single-vertex per-bin gradient: output indexed by the tap's bin
+                        const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
+                        const V3 ce0 = cross(gv.t2, e0), ce1 = cross(gv.t2, e1), ce2 = cross(gv.t2, e2);
                         V3 ce; float bw;
                         if (a.vertex_num == f.i0) { ce = ce0; bw = g.u; }
                         else if (a.vertex_num == f.i1) { ce = ce1; bw = g.v; }
@@ -299,19 +326,12 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                         grouped_taps(tt, s_diff, T, twoh, lbd, resd, inv_res, s0, s1);
                         di = g.dir * gv.inten_f;
                     }
-                    const float bw[3] = {g.u, g.v, g.w};
-                    const V3 ce[3] = {ce0, ce1, ce2};
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        V3 A1 = grad_axpy(gv.t1, bw[q], ce[q]);
-                        V3 A2 = di * bw[q];
-                        acc[3 * q + 0] = fma((double)A1.x, s0, fma((double)A2.x, s1, acc[3 * q + 0]));
-                        acc[3 * q + 1] = fma((double)A1.y, s0, fma((double)A2.y, s1, acc[3 * q + 1]));
-                        acc[3 * q + 2] = fma((double)A1.z, s0, fma((double)A2.z, s1, acc[3 * q + 2]));
-                    }
+                    fs.add(gv.t1, gv.t2, di, g.u, g.v, g.w, s0, s1);
                 }
             }
             if (MODE == 0 || MODE == 4) {
+                double acc[9];
+                fs.finish(f, acc);
                 const double sc = (double)f.area / (double)spt;
                 const int vi[3] = {f.i0, f.i1, f.i2};
 #pragma unroll
