@@ -151,8 +151,12 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
         typedef float f2_t __attribute__((ext_vector_type(2)));
         const f2_t* geo_w = GEO ? reinterpret_cast<const f2_t*>(a.geo + 4 * (size_t)a.geo_sources * (size_t)a.geo_stride) + (size_t)l * (size_t)a.geo_stride : nullptr;
         const int n_src = it_l ? (int)(it_l[0] & 0xffffull) : F;
-        // faces with at least one accepted sample, compacted in order (pass 1 left the masks)
-        for (int b = wave; b < nblocks; b += nwaves) {
+        // Per-face words: faces with at least one accepted sample, compacted in order (pass 1 left the words).  Item masks: no
+        // compaction (round 5) -- a lane takes a live-list ENTRY as it stands and an entry without accepted samples idles its
+        // lane for one block: with pass 2's sample loop at half of its round-4 length the three passes and barriers of the
+        // compaction cost more than the 11 % of idle lanes they saved (0.3634 -> 0.3485 ms, profiles/r05_ab_grad_sources.log).
+        const bool skip_compact = it_l != nullptr;
+        for (int b = wave; !skip_compact && b < nblocks; b += nwaves) {
             const int j = (b << 6) + lane;
             uint32_t any = 0;
             if (j < n_src) {
@@ -166,8 +170,8 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
             const unsigned long long m = __ballot(any != 0u);
             if (lane == 0) s_mask[b] = m;
         }
-        __syncthreads();
-        if (threadIdx.x < 64) {
+        if (!skip_compact) __syncthreads();
+        if (!skip_compact && threadIdx.x < 64) {
             // wave 0: exclusive scan of the per-block counts
             uint32_t run = 0;
             for (int b0 = 0; b0 < nblocks; b0 += 64) {
@@ -183,14 +187,14 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
             }
             if (lane == 0) s_base[nblocks] = run;
         }
-        __syncthreads();
-        for (int b = wave; b < nblocks; b += nwaves) {
+        if (!skip_compact) __syncthreads();
+        for (int b = wave; !skip_compact && b < nblocks; b += nwaves) {
             const unsigned long long m = s_mask[b];
             if (a.compact && ((m >> lane) & 1ull))
                 s_live[s_base[b] + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((b << 6) + lane);
         }
         __syncthreads();
-        const int n_live = a.compact ? (int)s_base[nblocks] : n_src;
+        const int n_live = (a.compact && !skip_compact) ? (int)s_base[nblocks] : n_src;
         const int live_blocks = (n_live + 63) >> 6;
         // measurement l: source l, pair l, or -- pass 2 of the L x S product -- the pair (laser l / S, sensor l % S)
         const size_t la = (NC && a.src.n_sensors > 0) ? (size_t)(l / a.src.n_sensors) : (size_t)l;
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
             if (b >= live_blocks) break;
             const int li = (b << 6) + lane;
             if (li >= n_live) continue;
-            const int e = a.compact ? (int)s_live[li] : li;          // a face slot, or (item masks) an entry of the live list
+            const int e = (a.compact && !skip_compact) ? (int)s_live[li] : li;          // a face slot, or (item masks) an entry of the live list
             const int j = it_l ? (int)live_l[e] : e;
             const uint32_t* visp = it_l ? nullptr : a.vis + ((size_t)l * a.vis_words) * F + j;
             const uint32_t ibits = it_l ? item_bits(it_l, e, spt) : 0u;
