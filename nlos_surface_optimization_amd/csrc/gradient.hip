@@ -155,7 +155,9 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
         // compaction (round 5) -- a lane takes a live-list ENTRY as it stands and an entry without accepted samples idles its
         // lane for one block: with pass 2's sample loop at half of its round-4 length the three passes and barriers of the
         // compaction cost more than the 11 % of idle lanes they saved (0.3634 -> 0.3485 ms, profiles/r05_ab_grad_sources.log).
-        const bool skip_compact = it_l != nullptr;
+        // (pairs keep the compaction: their samples are regenerated -- two legs, two triangle tests -- and an idle lane costs
+        // that much more: 0.555 vs 0.588 ms without)
+        const bool skip_compact = it_l != nullptr && !NC;
         for (int b = wave; !skip_compact && b < nblocks; b += nwaves) {
             const int j = (b << 6) + lane;
             uint32_t any = 0;
