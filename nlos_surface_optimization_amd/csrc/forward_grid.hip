@@ -233,34 +233,7 @@ __device__ __forceinline__ void raster_tri_coarse(const GridView& g, int R2, con
 #endif
 }
 
-// Slope-space frame of a source: bounding rectangle of the projection of the BVH's (padded) root box.
-// Shared by the grid kernel and the tile-binning kernel, which must agree bit for bit.
-struct SourceFrame { bool ok; float gx0, gy0, wx, wy, zr0, zr1, hmin; };
-__device__ __forceinline__ SourceFrame source_frame(const float4* __restrict__ nodes, V3 o) {
-    SourceFrame fr;
-    const float4 ra = nodes[0], rb = nodes[1];
-    fr.zr0 = ra.z - o.z;
-    fr.zr1 = rb.y - o.z;
-    const float ext = fmaxf(fmaxf(ra.w - ra.x, rb.x - ra.y), rb.y - ra.z);
-    fr.ok = fr.zr0 > 0.02f * ext && fr.zr0 > 0.0f;
-    const float i0 = 1.0f / fmaxf(fr.zr0, 1e-30f), i1 = 1.0f / fmaxf(fr.zr1, 1e-30f);
-    const float xl = ra.x - o.x, xh = ra.w - o.x, yl = ra.y - o.y, yh = rb.x - o.y;
-    const float gx0 = fminf(xl * i0, xl * i1), gx1 = fmaxf(xh * i0, xh * i1);
-    const float gy0 = fminf(yl * i0, yl * i1), gy1 = fmaxf(yh * i0, yh * i1);
-    fr.wx = fmaxf(gx1 - gx0, 1e-12f);
-    fr.wy = fmaxf(gy1 - gy0, 1e-12f);
-    fr.gx0 = gx0 - 1e-3f * fr.wx;
-    fr.gy0 = gy0 - 1e-3f * fr.wy;
-    // graze_scale(): plane distance below which a triangle of this scene can be seen at |cos| < 2^-6 (x 1.1)
-    const float fx = fmaxf(fabsf(xl), fabsf(xh)), fy = fmaxf(fabsf(yl), fabsf(yh)), fz = fmaxf(fabsf(fr.zr0), fabsf(fr.zr1));
-    fr.hmin = sqrtf(fx * fx + fy * fy + fz * fz) * (1.1f / 64.0f);
-    // The grid trace evaluates its square roots, reciprocals and divisions in the lean forms of nlos_device.h, which are the
-    // IEEE results for operands between 2^-60 and 2^60: every vertex at least 2^-29 in front of the wall point and at most
-    // 2^28 away along every axis keeps |p - o|^2, |p - o|, the edge cross products and their reciprocals inside that range.
-    // (A scene outside it -- nanometres or light-seconds in a renderer of metre-sized objects -- takes the BVH query.)
-    fr.ok = fr.ok && fr.zr0 >= 0x1p-29f && fmaxf(fmaxf(fx, fy), fz) <= 0x1p28f;
-    return fr;
-}
+// (SourceFrame / source_frame(): render_common.h -- pass 2 asks the same question about a source's arithmetic range)
 
 // Tile binning for the tiled grid: one workgroup per source appends every triangle to the subset of each
 // slope-space tile its projected bounding box meets (with the rasteriser's margin).  O(F) per source -- the
@@ -1326,12 +1299,6 @@ __global__ __launch_bounds__(kGridNT, kGridNT / 128) void k_forward_grid(Forward
 // LDS budget of the grid kernel: two 512-thread workgroups per CU -- 160 KiB / 2, minus the kernel's static
 // arrays (s_scan 2 KiB, s_bkt 128 B); one byte more and only one workgroup fits a CU (2.4 -> 3.9 ms)
 constexpr size_t kGridLdsBudget = 78 * 1024 - 128 - (kGridNT - 512) * 4;
-
-// The grid trace divides by `res` in the lean form (nlos_device.h: div_by), exact for 2^-30 <= res <= 2^30 and path
-// lengths below 2^29; a time window outside that range is rendered through the BVH back-end (reason 7).
-inline bool lean_params_ok(const SampleParams& sp) {
-    return sp.res >= 0x1p-30f && sp.res <= 0x1p30f && fabsf(sp.lb) <= 0x1p29f && fabsf(sp.ub) <= 0x1p29f;
-}
 
 template <int FEAT, int NCM = 0>
 bool forward_grid_launch(const ForwardArgs& a_in, int rows_in_lds, hipStream_t stream) {

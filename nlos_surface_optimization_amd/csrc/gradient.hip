@@ -206,6 +206,10 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
         const V3 ob = NC ? ld3(a.src.sensor + 3 * lb_) : o;
         const V3 onb = NC ? ld3(a.src.sensor_normal + 3 * lb_) : on;
         const uint64_t lg = (uint64_t)(a.src.source_offset + (long long)l * a.src.source_stride);
+        // regenerated samples (no geometry cache): the draw keyed per source like pass 1's, and the lean forms of sqrt / reciprocal
+        // where this source's frame and the window guarantee their range (render_common.h: sample_geo_keyed) -- the same bits
+        const uint64_t zbase = sample_zbase(a.sp.seed, lg * (uint64_t)F * (uint64_t)spt);
+        const bool lean_src = !GEO && !NC && a.lean_params && source_frame(a.sc.nodes, o).ok;
 
         for (;;) {
             const int b = wave_ticket(s_next);
@@ -267,8 +271,8 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                     float t_self;
                     if (GEO) {
                         cached_geo<FEAT>(f, cdir, cv, cw, ch, a.sc.vertex_normal, a.sc.albedo, g);
-                    } else if (!sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)s, a.sp.lb, a.sp.ub,
-                                                 a.sc.vertex_normal, a.sc.albedo, g, t_self))
+                    } else if (!sample_geo_keyed<FEAT>(f, tr, o, zbase, (uint32_t)f.fid * (uint32_t)spt + (uint32_t)s, lean_src, a.sp.lb, a.sp.ub,
+                                                       a.sc.vertex_normal, a.sc.albedo, g, t_self))
                         continue;   // cannot happen: pass 1 accepted this sample with the same arithmetic
                     const double twoh = (double)(2.0f * g.h);
                     if (MODE == 1 || MODE == 2) {
@@ -422,7 +426,8 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
     }
     TapTables tt;
     tt.delta = s_delta; tt.p0 = s_p0; tt.p1 = s_p1; tt.K = K; tt.two_rs = a.two_rs; tt.r_over_res = a.r_over_res; tt.refine = a.refine;
-    tt.wt = nullptr; tt.nb = 0;             // (the face-major kernel keeps the boundary arithmetic: its LDS is full)
+    // (its LDS is full: the 880 bytes of tabulated bin weights are read through the cache)
+    tt.wt = (!JIT && a.tap_wt && a.tap_nb > 0 && K > 1) ? a.tap_wt : nullptr; tt.nb = a.tap_nb;
 
     for (int lb0 = l0; lb0 < l1; lb0 += kFmBatch) {
         const int nb = min(kFmBatch, l1 - lb0);
@@ -459,17 +464,18 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
             const size_t lsn = (NC && a.src.n_sensors > 0) ? (size_t)(l % a.src.n_sensors) : (size_t)l;
             const V3 o = ld3(a.src.origin + 3 * la);
             const V3 on = ld3(a.src.normal + 3 * la);
-            const uint64_t kbase = ((uint64_t)(a.src.source_offset + (long long)l * a.src.source_stride) * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
+            const uint64_t lgf = (uint64_t)(a.src.source_offset + (long long)l * a.src.source_stride);
+            const uint64_t kbase = (lgf * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
+            const uint64_t zbase = sample_zbase(a.sp.seed, lgf * (uint64_t)F * (uint64_t)spt);
+            const bool lean_src = !NC && a.lean_params && source_frame(a.sc.nodes, o).ok;      // (per lane here: items mix sources)
             const uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
-            double acc[9];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) acc[q] = 0.0;
+            FaceSums fs;
+            fs.clear();
             for (int wi = 0; wi < a.vis_words; ++wi) {
                 uint32_t word = visp[(size_t)wi * F];
                 while (word) {
                     const int bit = __ffs(word) - 1;
                     word &= word - 1;
-                    const V3 e0 = f.p2 - f.p1, e1 = f.p0 - f.p2, e2 = f.p1 - f.p0;
                     GVec gv;
                     V3 di;
                     float bw[3];
@@ -490,8 +496,8 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
                     } else {
                         Geo g;
                         float t_self;
-                        if (!sample_geo<FEAT>(f, tr, o, a.sp.seed, kbase + (uint64_t)((wi << 5) + bit), a.sp.lb, a.sp.ub,
-                                              a.sc.vertex_normal, a.sc.albedo, g, t_self))
+                        if (!sample_geo_keyed<FEAT>(f, tr, o, zbase, (uint32_t)f.fid * (uint32_t)spt + (uint32_t)((wi << 5) + bit), lean_src,
+                                                    a.sp.lb, a.sp.ub, a.sc.vertex_normal, a.sc.albedo, g, t_self))
                             continue;
                         grad_vectors<FEAT>(f, g, on, a.normal_term, a.v1_style, a.sp.ggx_alpha, gv);
                         di = JIT ? g.dir : g.dir * gv.inten_f;
@@ -499,7 +505,6 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
                         twoh = (double)(2.0f * g.h);
                         jit_b0 = (int)floorf((2.0f * g.h - a.sp.lb) / a.sp.res) - a.two_rs;
                     }
-                    const V3 ce[3] = {cross(gv.t2, e0), cross(gv.t2, e1), cross(gv.t2, e2)};
                     double s0, s1;
                     if (JIT) {
                         // jitter/transient_and_gradient.cpp:944-969, as in k_gradient<FEAT, 4>
@@ -515,16 +520,11 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
                     } else {
                         grouped_taps(tt, s_diff, T, twoh, lbd, resd, inv_res, s0, s1);
                     }
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const V3 A1 = grad_axpy(gv.t1, bw[q], ce[q]);
-                        const V3 A2 = di * bw[q];
-                        acc[3 * q + 0] = fma((double)A1.x, s0, fma((double)A2.x, s1, acc[3 * q + 0]));
-                        acc[3 * q + 1] = fma((double)A1.y, s0, fma((double)A2.y, s1, acc[3 * q + 1]));
-                        acc[3 * q + 2] = fma((double)A1.z, s0, fma((double)A2.z, s1, acc[3 * q + 2]));
-                    }
+                    fs.add(gv.t1, gv.t2, di, bw[0], bw[1], bw[2], s0, s1);
                 }
             }
+            double acc[9];
+            fs.finish(f, acc);
 #pragma unroll
             for (int q = 0; q < 9; ++q) unsafeAtomicAdd(&s_acc[9 * jl + q], acc[q]);
         }
@@ -654,6 +654,7 @@ void launch_gradient(const GradientArgs& a_in, hipStream_t stream) {
     const size_t nblk = ((size_t)a.sc.F + 63) / 64;
     size_t lds = 8 + ((size_t)a.sp.nbins + 3 * (size_t)a.K + 2) * sizeof(double) + nblk * 8 + ((nblk + 2) & ~(size_t)1) * 4;
     // per-bin tap weights beside the prefix sums (TapTables::wt) while the table is small (refine 10, sigma_bin 1: 880 B)
+    a.lean_params = lean_params_ok(a.sp) ? 1 : 0;
     a.wt_in_lds = 0;
     if (a.mode == 0 && a.tap_wt && a.tap_nb > 0 && a.K > 1) {
         const size_t wt = sizeof(double) * 2 * (size_t)(a.refine + 1) * (size_t)a.tap_nb;

@@ -234,6 +234,7 @@ struct GradientArgs {
     const double* tap_wt;    // [(refine + 1) * tap_nb * 2] per-bin weights by first-boundary tap (render_common.h, TapTables::wt) or null
     int tap_nb;              // 4 sigma_bin + 1
     int wt_in_lds;           // set by launch_gradient: k_gradient stages tap_wt in LDS
+    int lean_params;         // set by launch_gradient: the window lies in the range of the lean arithmetic (render_common.h: lean_params_ok)
     int K;
     int two_rs;              // 2*refine*sigma_bin (index of the centre tap)
     double r_over_res;       // refine / resolution

@@ -141,6 +141,54 @@ __device__ __forceinline__ void cached_geo(const Face& f, V3 dir, float hv, floa
     if (FEAT & FEAT_ALB) g.alb = g.u * alb[f.i0] + g.v * alb[f.i1] + g.w * alb[f.i2];
 }
 
+// Slope-space frame of a source: bounding rectangle of the projection of the BVH's (padded) root box.
+// Shared by the grid kernel and the tile-binning kernel, which must agree bit for bit.
+struct SourceFrame { bool ok; float gx0, gy0, wx, wy, zr0, zr1, hmin; };
+__device__ __forceinline__ SourceFrame source_frame(const float4* __restrict__ nodes, V3 o) {
+    SourceFrame fr;
+    const float4 ra = nodes[0], rb = nodes[1];
+    fr.zr0 = ra.z - o.z;
+    fr.zr1 = rb.y - o.z;
+    const float ext = fmaxf(fmaxf(ra.w - ra.x, rb.x - ra.y), rb.y - ra.z);
+    fr.ok = fr.zr0 > 0.02f * ext && fr.zr0 > 0.0f;
+    const float i0 = 1.0f / fmaxf(fr.zr0, 1e-30f), i1 = 1.0f / fmaxf(fr.zr1, 1e-30f);
+    const float xl = ra.x - o.x, xh = ra.w - o.x, yl = ra.y - o.y, yh = rb.x - o.y;
+    const float gx0 = fminf(xl * i0, xl * i1), gx1 = fmaxf(xh * i0, xh * i1);
+    const float gy0 = fminf(yl * i0, yl * i1), gy1 = fmaxf(yh * i0, yh * i1);
+    fr.wx = fmaxf(gx1 - gx0, 1e-12f);
+    fr.wy = fmaxf(gy1 - gy0, 1e-12f);
+    fr.gx0 = gx0 - 1e-3f * fr.wx;
+    fr.gy0 = gy0 - 1e-3f * fr.wy;
+    // graze_scale(): plane distance below which a triangle of this scene can be seen at |cos| < 2^-6 (x 1.1)
+    const float fx = fmaxf(fabsf(xl), fabsf(xh)), fy = fmaxf(fabsf(yl), fabsf(yh)), fz = fmaxf(fabsf(fr.zr0), fabsf(fr.zr1));
+    fr.hmin = sqrtf(fx * fx + fy * fy + fz * fz) * (1.1f / 64.0f);
+    // The grid trace evaluates its square roots, reciprocals and divisions in the lean forms of nlos_device.h, which are the
+    // IEEE results for operands between 2^-60 and 2^60: every vertex at least 2^-29 in front of the wall point and at most
+    // 2^28 away along every axis keeps |p - o|^2, |p - o|, the edge cross products and their reciprocals inside that range.
+    // (A scene outside it -- nanometres or light-seconds in a renderer of metre-sized objects -- takes the BVH query.)
+    fr.ok = fr.ok && fr.zr0 >= 0x1p-29f && fmaxf(fmaxf(fx, fy), fz) <= 0x1p28f;
+    return fr;
+}
+
+// The grid trace divides by `res` in the lean form (nlos_device.h: div_by), exact for 2^-30 <= res <= 2^30 and path
+// lengths below 2^29; a time window outside that range is rendered through the BVH back-end (reason 7).
+inline bool lean_params_ok(const SampleParams& sp) {
+    return sp.res >= 0x1p-30f && sp.res <= 0x1p30f && fabsf(sp.lb) <= 0x1p29f && fabsf(sp.ub) <= 0x1p29f;
+}
+
+// Pass 2's regenerated samples (no geometry cache: pairs excluded, spt > 8, jitter, scalar modes, per-face-word layouts) in the
+// lean forms as well, where the source's frame and the launch's window guarantee the operand range: the same bits as pass 1's,
+// whichever form pass 1 itself used.  `lean` is wave-uniform (a property of the source).
+template <int FEAT>
+__device__ __forceinline__ bool sample_geo_keyed(const Face& f, const Tri& tr, V3 o, uint64_t zbase, uint32_t c, bool lean,
+                                                 float lb, float ub, const float* __restrict__ vn,
+                                                 const float* __restrict__ alb, Geo& g, float& t_self) {
+    float S, T;
+    sample_st_c(zbase, c, S, T);
+    return lean ? sample_geo_st<FEAT, true>(f, tr, o, S, T, lb, ub, vn, alb, g, t_self)
+                : sample_geo_st<FEAT, false>(f, tr, o, S, T, lb, ub, vn, alb, g, t_self);
+}
+
 __device__ __forceinline__ float emax0(float x) { return 0.0f < x ? x : 0.0f; }
 
 // fp64 add into a row held in LDS, as ds_add_f64 whatever the optimiser thinks of the surrounding branches.  Written as
