@@ -825,6 +825,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
 #endif
     const uint64_t kbase0 = lg * (uint64_t)F;
     const uint64_t zbase = sample_zbase(a.sp.seed, kbase0 * (uint64_t)spt);      // sample_st_c(): key = kbase0 spt + (fid spt + s)
+    const bool lean_b = NCM == 2 ? source_frame(a.sc.nodes, ob).ok : true;        // pairs: the sensor's frame (the laser's is frame_ok)
     const float rres = rcp_refined(res);                                          // div_by(x, res, rres) == x / res (launcher: res within the lean range)
     const double inv_spt = 1.0 / (double)spt;
 #ifdef NLOS_FWD_STAMPS
@@ -926,14 +927,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     ok = sample_geo_st<FEAT, LEAN>(f, tr, o, S, T, lb, ub, a.sc.vertex_normal, a.sc.albedo, gg, t_self);
                 }
                 if (ok) {
-                    const float num = -dot(gg.n, gg.dir) * dot(on, gg.dir);
-                    float ff;
-                    if (LEAN && __builtin_expect(fabsf(num) >= kLeanMin && fabsf(num) <= kLeanNumMax, 1)) {
-                        const float rh = rcp_refined(gg.h);
-                        ff = div_by(div_by(num, gg.h, rh), gg.h, rh);
-                    } else {
-                        ff = num / gg.h / gg.h;
-                    }
+                    float ff = form_factor<LEAN>(-dot(gg.n, gg.dir) * dot(on, gg.dir), gg.h);
                     if (a.sp.clamp) {
                         ff = emax0(ff);
                         ok = ff > 0.0f;
@@ -968,51 +962,58 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 // record pass of the product (row N as L x S): this wall point's leg of every pair it takes part in --
                 // the expressions of sample_geo_nc() for one end point.  Path length of the leg and its clamped form factor
                 // travel through the trace in `bin` / `val` and are stored for the samples the wall point sees.
+                // (GRID: the lean forms, as in the confocal branch -- this wall point's frame guarantees their range)
+                constexpr bool LEAN = GRID;
                 if (ok) {
                     float S, T;
                     sample_st(a.sp.seed, key, S, T);
-                    const float sq = sqrtf(T);
+                    const float sq = LEAN ? sqrt_cr0(T) : sqrtf(T);
                     const V3 p = bary(1 - sq, f.p0, (1 - S) * sq, f.p1, S * sq, f.p2);
                     const V3 d = p - o;
-                    dir = d * (1.0f / sqrtf(dot(d, d)));
+                    dir = d * (LEAN ? rcp_cr(sqrt_cr(dot(d, d))) : 1.0f / sqrtf(dot(d, d)));
                     float hu, hv;
-                    ok = tri_test(tr, o, dir, t_self, hu, hv);
+                    ok = tri_test<LEAN>(tr, o, dir, t_self, hu, hv);
                     if (ok) {
                         const V3 q = bary(1.0f - hu - hv, f.p0, hu, f.p1, hv, f.p2);
                         const V3 e = q - o;
-                        const float dist = sqrtf(dot(e, e));
-                        val = emax0(-dot(f.fn, dir) * dot(on, dir) / dist / dist);
+                        const float dist = LEAN ? sqrt_cr(dot(e, e)) : sqrtf(dot(e, e));
+                        val = emax0(form_factor<LEAN>(-dot(f.fn, dir) * dot(on, dir), dist));
                         bin = __float_as_int(dist);
                         ok = val > 0.0f;
                     }
                 }
             } else if (NCM == 1) {
                 // sensor leg only: is the stratified point the closest hit seen from the sensor?
+                constexpr bool LEAN = GRID;
                 if (ok) {
                     float S, T;
                     sample_st(a.sp.seed, key, S, T);
-                    const float sq = sqrtf(T);
+                    const float sq = LEAN ? sqrt_cr0(T) : sqrtf(T);
                     const V3 p = bary(1 - sq, f.p0, (1 - S) * sq, f.p1, S * sq, f.p2);
                     const V3 d = p - o;
-                    dir = d * (1.0f / sqrtf(dot(d, d)));
+                    dir = d * (LEAN ? rcp_cr(sqrt_cr(dot(d, d))) : 1.0f / sqrtf(dot(d, d)));
                     float hu, hv;
-                    ok = tri_test(tr, o, dir, t_self, hu, hv);
+                    ok = tri_test<LEAN>(tr, o, dir, t_self, hu, hv);
                     // a leg whose form factor is exactly zero is rejected by the laser pass anyway: skip its ray
                     if (ok && !(FEAT & FEAT_VN)) ok = (-dot(f.fn, dir) * dot(on, dir)) > 0.0f;
                 }
             } else {
                 GeoNC gc;
                 float t_b;
+                // (the lean forms where the laser's frame -- GRID -- and the sensor's -- lean_b, evaluated once per workgroup --
+                // both guarantee the range)
+                const bool lean_nc = GRID && lean_b;
                 if (ok)
-                    ok = sample_geo_nc<FEAT>(f, tr, o, ob, a.sp.seed, key, lb, ub, a.sc.vertex_normal, a.sc.albedo, gc, t_self, t_b);
+                    ok = sample_geo_nc_rt<FEAT>(f, tr, o, ob, a.sp.seed, key, lean_nc, lb, ub, a.sc.vertex_normal, a.sc.albedo, gc, t_self, t_b);
                 if (ok) {
                     const uint32_t word_b = a.vis2[((size_t)l * a.vis_words + (size_t)(s >> 5)) * F + jg];
-                    const float ffa = emax0(-dot(gc.n, gc.dirA) * dot(on, gc.dirA) / gc.d1 / gc.d1);
-                    const float ffb = emax0(-dot(gc.n, gc.dirB) * dot(onb, gc.dirB) / gc.d2 / gc.d2);
+                    const float numa = -dot(gc.n, gc.dirA) * dot(on, gc.dirA), numb = -dot(gc.n, gc.dirB) * dot(onb, gc.dirB);
+                    const float ffa = emax0(lean_nc ? form_factor<true>(numa, gc.d1) : form_factor<false>(numa, gc.d1));
+                    const float ffb = emax0(lean_nc ? form_factor<true>(numb, gc.d2) : form_factor<false>(numb, gc.d2));
                     ok = ffa > 0.0f && ffb > 0.0f && ((word_b >> (s & 31)) & 1u);
                     val = f.area * gc.alb * ffa * ffb;
                     if (FEAT & FEAT_GGX) val = val * ggx_pair<false>(a.sp.ggx_alpha, gc.n, -gc.dirA, -gc.dirB).brdf;
-                    bin = (int)floorf(((gc.d1 + gc.d2) - lb) / res);
+                    bin = (int)floorf(lean_nc ? div_by((gc.d1 + gc.d2) - lb, res, rres) : ((gc.d1 + gc.d2) - lb) / res);
                     dir = gc.dirA;
                 }
             }

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
         // regenerated samples (no geometry cache): the draw keyed per source like pass 1's, and the lean forms of sqrt / reciprocal
         // where this source's frame and the window guarantee their range (render_common.h: sample_geo_keyed) -- the same bits
         const uint64_t zbase = sample_zbase(a.sp.seed, lg * (uint64_t)F * (uint64_t)spt);
-        const bool lean_src = !GEO && !NC && a.lean_params && source_frame(a.sc.nodes, o).ok;
+        const bool lean_src = !GEO && a.lean_params && source_frame(a.sc.nodes, o).ok && (!NC || source_frame(a.sc.nodes, ob).ok);
 
         for (;;) {
             const int b = wave_ticket(s_next);
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                         // row N: two legs, d(d1 + d2)/dp = dirA + dirB; P1 carries the confocal factor 2
                         GeoNC gc;
                         float tA, tB;
-                        if (!sample_geo_nc<FEAT>(f, tr, o, ob, a.sp.seed, kbase + (uint64_t)s, a.sp.lb, a.sp.ub,
-                                                 a.sc.vertex_normal, a.sc.albedo, gc, tA, tB))
+                        if (!sample_geo_nc_rt<FEAT>(f, tr, o, ob, a.sp.seed, kbase + (uint64_t)s, lean_src, a.sp.lb, a.sp.ub,
+                                                    a.sc.vertex_normal, a.sc.albedo, gc, tA, tB))
                             continue;
                         GVec gv;
                         grad_vectors_nc<FEAT>(f, gc, on, onb, a.normal_term, a.sp.ggx_alpha, gv);
@@ -467,7 +467,8 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
             const uint64_t lgf = (uint64_t)(a.src.source_offset + (long long)l * a.src.source_stride);
             const uint64_t kbase = (lgf * (uint64_t)F + (uint64_t)f.fid) * (uint64_t)spt;
             const uint64_t zbase = sample_zbase(a.sp.seed, lgf * (uint64_t)F * (uint64_t)spt);
-            const bool lean_src = !NC && a.lean_params && source_frame(a.sc.nodes, o).ok;      // (per lane here: items mix sources)
+            const V3 obf = NC ? ld3(a.src.sensor + 3 * lsn) : o;
+            const bool lean_src = a.lean_params && source_frame(a.sc.nodes, o).ok && (!NC || source_frame(a.sc.nodes, obf).ok);      // (per lane here: items mix sources)
             const uint32_t* visp = a.vis + ((size_t)l * a.vis_words) * F + j;
             FaceSums fs;
             fs.clear();
@@ -485,9 +486,8 @@ __global__ __launch_bounds__(kFmThreads, NLOS_FM_WPS) void k_gradient_fm(Gradien
                         // row N: two legs, d(d1 + d2)/dp = dirA + dirB; P1 carries the confocal factor 2
                         GeoNC gc;
                         float tA, tB;
-                        if (!sample_geo_nc<FEAT>(f, tr, o, ld3(a.src.sensor + 3 * lsn), a.sp.seed,
-                                                 kbase + (uint64_t)((wi << 5) + bit), a.sp.lb, a.sp.ub, a.sc.vertex_normal,
-                                                 a.sc.albedo, gc, tA, tB))
+                        if (!sample_geo_nc_rt<FEAT>(f, tr, o, obf, a.sp.seed, kbase + (uint64_t)((wi << 5) + bit), lean_src, a.sp.lb, a.sp.ub,
+                                                    a.sc.vertex_normal, a.sc.albedo, gc, tA, tB))
                             continue;
                         grad_vectors_nc<FEAT>(f, gc, on, ld3(a.src.sensor_normal + 3 * lsn), a.normal_term, a.sp.ggx_alpha, gv);
                         di = ((gc.dirA + gc.dirB) * 0.5f) * gv.inten_f;

@@ -176,6 +176,17 @@ inline bool lean_params_ok(const SampleParams& sp) {
     return sp.res >= 0x1p-30f && sp.res <= 0x1p30f && fabsf(sp.lb) <= 0x1p29f && fabsf(sp.ub) <= 0x1p29f;
 }
 
+// num / h / h, the (unclamped) form factor of a leg of length h.  LEAN: through one refined reciprocal of h where the numerator
+// lies in the range on which div_by() is the IEEE division (nlos_device.h); the rare lane outside takes the IEEE form.  Same bits.
+template <bool LEAN>
+__device__ __forceinline__ float form_factor(float num, float h) {
+    if (LEAN && __builtin_expect(fabsf(num) >= kLeanMin && fabsf(num) <= kLeanNumMax, 1)) {
+        const float rh = rcp_refined(h);
+        return div_by(div_by(num, h, rh), h, rh);
+    }
+    return num / h / h;
+}
+
 // Pass 2's regenerated samples (no geometry cache: pairs excluded, spt > 8, jitter, scalar modes, per-face-word layouts) in the
 // lean forms as well, where the source's frame and the launch's window guarantee the operand range: the same bits as pass 1's,
 // whichever form pass 1 itself used.  `lean` is wave-uniform (a property of the source).
@@ -222,34 +233,36 @@ struct GeoNC {
     float alb;
 };
 
-template <int FEAT>
+// LEAN: the lean forms of sqrt / reciprocal (nlos_device.h) -- the same bits where BOTH wall points' frames guarantee the
+// operand range (source_frame() of the laser and of the sensor; the callers check both).
+template <int FEAT, bool LEAN = false>
 __device__ __forceinline__ bool sample_geo_nc(const Face& f, const Tri& tr, V3 oa, V3 ob, uint64_t seed, uint64_t k,
                                               float lb, float ub, const float* __restrict__ vn,
                                               const float* __restrict__ alb, GeoNC& g, float& tA, float& tB) {
     float S, T;
     sample_st(seed, k, S, T);
-    float sq = sqrtf(T);
+    float sq = LEAN ? sqrt_cr0(T) : sqrtf(T);
     float u = 1 - sq;
     float v = (1 - S) * sq;
     float w = S * sq;
     V3 p = bary(u, f.p0, v, f.p1, w, f.p2);
     V3 dA = p - oa;
-    g.dirA = dA * (1.0f / sqrtf(dot(dA, dA)));
+    g.dirA = dA * (LEAN ? rcp_cr(sqrt_cr(dot(dA, dA))) : 1.0f / sqrtf(dot(dA, dA)));
     float hu, hv;
-    if (!tri_test(tr, oa, g.dirA, tA, hu, hv)) return false;
+    if (!tri_test<LEAN>(tr, oa, g.dirA, tA, hu, hv)) return false;
     g.v = hu;
     g.w = hv;
     g.u = 1.0f - g.v - g.w;
     V3 qA = bary(g.u, f.p0, g.v, f.p1, g.w, f.p2);
     V3 eA = qA - oa;
-    g.d1 = sqrtf(dot(eA, eA));
+    g.d1 = LEAN ? sqrt_cr(dot(eA, eA)) : sqrtf(dot(eA, eA));
     V3 dB = p - ob;
-    g.dirB = dB * (1.0f / sqrtf(dot(dB, dB)));
+    g.dirB = dB * (LEAN ? rcp_cr(sqrt_cr(dot(dB, dB))) : 1.0f / sqrtf(dot(dB, dB)));
     float bu, bv;
-    if (!tri_test(tr, ob, g.dirB, tB, bu, bv)) return false;
+    if (!tri_test<LEAN>(tr, ob, g.dirB, tB, bu, bv)) return false;
     V3 qB = bary(1.0f - bu - bv, f.p0, bu, f.p1, bv, f.p2);
     V3 eB = qB - ob;
-    g.d2 = sqrtf(dot(eB, eB));
+    g.d2 = LEAN ? sqrt_cr(dot(eB, eB)) : sqrtf(dot(eB, eB));
     const float tot = g.d1 + g.d2;
     if (!((tot <= ub) && (tot >= lb))) return false;
     g.n = f.fn;
@@ -260,6 +273,14 @@ __device__ __forceinline__ bool sample_geo_nc(const Face& f, const Tri& tr, V3 o
     g.alb = 1.0f;
     if (FEAT & FEAT_ALB) g.alb = g.u * alb[f.i0] + g.v * alb[f.i1] + g.w * alb[f.i2];
     return true;
+}
+// (wave-uniform choice of the form: a property of the pair)
+template <int FEAT>
+__device__ __forceinline__ bool sample_geo_nc_rt(const Face& f, const Tri& tr, V3 oa, V3 ob, uint64_t seed, uint64_t k, bool lean,
+                                                 float lb, float ub, const float* __restrict__ vn,
+                                                 const float* __restrict__ alb, GeoNC& g, float& tA, float& tB) {
+    return lean ? sample_geo_nc<FEAT, true>(f, tr, oa, ob, seed, k, lb, ub, vn, alb, g, tA, tB)
+                : sample_geo_nc<FEAT, false>(f, tr, oa, ob, seed, k, lb, ub, vn, alb, g, tA, tB);
 }
 
 // ------------------------------------------------------------------- gradient
