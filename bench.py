@@ -174,6 +174,67 @@ def parity_gate(render_block, n, t_ref, g_ref):
     return out
 
 
+def time_api_paths(args, r, backend, origin_np, normal_np, v_np, f_np, data_np, lb, ub, res, T,
+                   origin, normal, verts, faces, data, weight, grad):
+    """Side measurements on the metric workload, never `value`: (1) the host-pointer drop-in -- numpy arrays in and out
+    through the C ABI's section 1 (uploads of data / weight and the download of the rows are part of every call, as in the
+    reference); (2) the autograd pair -- TransientFunction.forward (pass 1, visibility kept) + a weighted-L2 loss in torch +
+    backward (pass 2 on the kept visibility).  Results of the drop-in are compared with the device path's (same seed)."""
+    import torch
+    from nlos_surface_optimization_amd import renderer as np_renderer
+    from nlos_surface_optimization_amd import device as nd
+    L = origin_np.shape[0]
+    V = v_np.shape[0]
+    n = args.dropin_steps
+    out = {}
+    # ---- numpy drop-in
+    w_np = np.ones_like(data_np)
+    tr_np = np.zeros((L, T))
+    path_np = np.zeros(T)
+    g_np = np.zeros((V, 3))
+
+    def call():
+        g_np[:] = 0.0
+        np_renderer.renderStreamedGradient(origin_np, normal_np, v_np, f_np, args.num_sample, lb, ub, res, tr_np, path_np,
+                                           g_np, data_np, w_np, 10, 1, 1, 0)
+    for _ in range(3):
+        call()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        call()
+    out["dropin_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / n
+    # same results as the device path (both use seed 0; the drop-in scales by 1 / L of its own call, like the bench step)
+    t_dev, g_dev, _ = r.render_gradient(origin, normal, verts, faces, args.num_sample, lb, ub, res, data=data, weight=weight,
+                                        refine_scale=10, sigma_bin=1, testing_flag=1, loss_flag=0, gradient=grad, zero_gradient=True)
+    backend.sync()
+    dt = float(np.abs(t_dev.cpu().numpy() - tr_np).max())
+    dg = float(np.abs(g_dev.cpu().numpy() - g_np).max() / max(float(np.abs(g_np).max()), 1e-300))
+    out["dropin"] = {"steps": n, "max_abs_row_difference_vs_device_path": dt, "max_rel_gradient_difference_vs_device_path": dg,
+                     "host_bytes_per_call": int(3 * L * T * 8 + 2 * L * 12 + V * 12 + f_np.size * 4 + V * 24),
+                     "entry": "renderer.renderStreamedGradient(numpy) -> nlos_streamed_render_gradient (include/nlos_hip.h section 1)"}
+    # ---- autograd pair
+    vt = verts.detach().clone().requires_grad_(True)
+
+    def ag():
+        if vt.grad is not None:
+            vt.grad = None
+        tr = nd.render_transient_autograd(r, vt, origin, normal, faces, args.num_sample, lb, ub, res, refine_scale=10, sigma_bin=1)
+        loss = (((tr - data) ** 2) * weight).sum() / L
+        loss.backward()
+    for _ in range(3):
+        ag()
+    backend.sync()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ag()
+    backend.sync()
+    out["autograd_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / n
+    ga = vt.grad.detach().to(torch.float64).cpu().numpy()
+    out["autograd"] = {"steps": n, "max_rel_gradient_difference_vs_device_path": float(np.abs(ga - g_dev.cpu().numpy()).max() / max(float(np.abs(ga).max()), 1e-300)),
+                       "entry": "device.render_transient_autograd: TransientFunction.forward (keep_visibility) + torch loss + backward (reuse_visibility)"}
+    return out
+
+
 def workload_config(args, g, T, F, V, spt, L_total, world):
     """The `config` object of the JSON line (names the workload; the side-measurement flags say so)."""
     return {
@@ -233,6 +294,11 @@ def parse_args(argv=None):
     ap.add_argument("--share-steps", type=int, default=10,
                     help="N = 1, metric workload: after the timed steps, time every rank's block of the 2-, 4- and 8-way strong "
                          "split for this many steps each and report them as `strong_share` (0 = skip)")
+    ap.add_argument("--dropin-steps", type=int, default=20,
+                    help="N = 1, metric workload: after the timed steps, time the same step through the reference-shaped host "
+                         "entry (renderer.renderStreamedGradient on numpy arrays: what main.py / exp_bunny/test.py call) and "
+                         "through the autograd pair (TransientFunction forward + backward) for this many steps each; reported "
+                         "as dropin_ms_per_step / autograd_ms_per_step (0 = skip)")
     ap.add_argument("--non-confocal", action="store_true",
                     help="row N side measurement (not the metric): every source becomes a (laser, sensor) pair, "
                          "sensor = laser + (0.05, -0.03, 0)")
@@ -503,6 +569,13 @@ def run_rank(args, backend):
             t_s = float(ts.item())
         sustained_ms = 1e3 * t_s / sustained_steps
 
+    # ---- the paths a user of the reference's API calls (round 6): the numpy drop-in (host arrays in, host arrays out, every
+    # call: transient_rendering_cython/main.py:114-115, exp_bunny/rendering.py:252-269) and the autograd pair ----
+    api_paths = None
+    if world == 1 and plain and args.dropin_steps > 0 and not diagnostic:
+        api_paths = time_api_paths(args, r, backend, origin_np, normal_np, v_np, f_np, data_np, lb, ub, res, T,
+                                   origin, normal, verts, faces, data, weight, grad)
+
     # ---- strong scaling, the part one GPU can time: every rank's block of the 2-, 4- and 8-way split of this very grid
     # (global source offsets, 1/L_total scaling, replicated scene build -- what a rank does per step, without the
     # all-reduce) ----
@@ -592,6 +665,8 @@ def run_rank(args, backend):
             out["as_rank"] = {"rank": args.as_rank, "of": args.of, "partition": partition, "first_source": lo, "source_stride": stride, "sources": L,
                               "note": "one GPU timing what rank %d of a %d-rank strong split does per step (no collective); "
                                       "`value` counts this block's samples only" % (args.as_rank, args.of)}
+        if api_paths is not None:
+            out.update(api_paths)
         if share is not None:
             share["note"] = ("measured on ONE GPU: every rank's sources of the N-way strong split of this grid, for both partitions "
                              "(contiguous blocks / every N-th source), %d steps each, "

@@ -139,6 +139,47 @@ constexpr int kQueueWords = kQueueCap + 3;  // + a dump slot for the lanes that 
 constexpr int kGridNT = NLOS_GRID_NT;
 constexpr int kGridWaves = kGridNT / 64;
 
+// Diagnostic builds only (tools/pad_test.sh, round 6): N extra VALU instructions at one point of the kernel -- what an
+// instruction costs IN SITU.  If the SIMDs' issue slots are saturated the launch grows by N x trips x the instruction's
+// issue cost / (SIMDs x clock); if they are not, by less: the slope is the share of an instruction's issue time that removing
+// it would give back.  OP 0 = v_add_u32 (full rate), 1 = v_lshlrev_b32, 2 = v_cmp_lt_u32, 3 = v_min_u32, 4 = v_mul_lo_u32 (half rate
+// back to back in tools/issue_rate.hip), 5 = v_fma_f32; two independent temporaries.
+#ifndef NLOS_DIAG_PAD_OP
+#define NLOS_DIAG_PAD_OP 0
+#endif
+template <int N>
+__device__ __forceinline__ void diag_pad() {
+    if constexpr (N > 0) {
+        uint32_t t0, t1;
+        asm volatile("v_mov_b32 %0, 1\n\tv_mov_b32 %1, 2" : "=v"(t0), "=v"(t1));
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+#if NLOS_DIAG_PAD_OP == 0
+            asm volatile("v_add_u32 %0, %0, %0\n\tv_add_u32 %1, %1, %1" : "+v"(t0), "+v"(t1));
+#elif NLOS_DIAG_PAD_OP == 1
+            asm volatile("v_lshlrev_b32 %0, 1, %0\n\tv_lshlrev_b32 %1, 1, %1" : "+v"(t0), "+v"(t1));
+#elif NLOS_DIAG_PAD_OP == 2
+            asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cmp_lt_u32 vcc, %1, %0" : "+v"(t0), "+v"(t1) : : "vcc");
+#elif NLOS_DIAG_PAD_OP == 3
+            asm volatile("v_min_u32 %0, %0, %1\n\tv_min_u32 %1, %1, %0" : "+v"(t0), "+v"(t1));
+#elif NLOS_DIAG_PAD_OP == 4
+            asm volatile("v_mul_lo_u32 %0, %0, %0\n\tv_mul_lo_u32 %1, %1, %1" : "+v"(t0), "+v"(t1));
+#else
+            asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1" : "+v"(t0), "+v"(t1));
+#endif
+        }
+    }
+}
+#ifndef NLOS_DIAG_PAD_WALK
+#define NLOS_DIAG_PAD_WALK 0
+#endif
+#ifndef NLOS_DIAG_PAD_GEN
+#define NLOS_DIAG_PAD_GEN 0
+#endif
+#ifndef NLOS_DIAG_PAD_COUNT
+#define NLOS_DIAG_PAD_COUNT 0
+#endif
+
 __device__ __forceinline__ uint32_t make_entry(const GridView& g, const BBoxF& bb, int xx, int yy, uint32_t zq, int k, float ms) {
     // the box is widened by ms x (kSubFrac sub-cells + kSlopeAbs) (g.padx, g.pady: in sub-cells; ms = graze_scale)
     const float px = g.padx * ms, py = g.pady * ms;
@@ -148,6 +189,30 @@ __device__ __forceinline__ uint32_t make_entry(const GridView& g, const BBoxF& b
     const float fy1 = ((bb.y1 - g.gy0) * g.inv_ch - (float)yy) * (float)kSub + py;
     const int a0 = min(max((int)floorf(fx0), 0), kSub - 1), a1 = min(max((int)floorf(fx1), 0), kSub - 1);
     const int b0 = min(max((int)floorf(fy0), 0), kSub - 1), b1 = min(max((int)floorf(fy1), 0), kSub - 1);
+    const uint32_t xm = (2u << a1) - (1u << a0), ym = (2u << b1) - (1u << b0);
+    return (zq << (g.ib + 2 * kSub)) | (ym << (g.ib + kSub)) | (xm << g.ib) | (uint32_t)k;
+}
+
+// The same entry from the triangle's box in GLOBAL sub-cell coordinates (round 6): the four floors are taken once per triangle
+// (sub_box()), an entry pays two integer subtractions and clamps per axis instead of four float subtract / scale / floor /
+// convert chains.  floor(((A - xx) kSub) - p) and floor(A kSub - p) - kSub xx differ by the rounding of A kSub (A < 96 cells:
+// 3e-5 sub-cells); kSubSlack on either side covers it -- the masks may only be too LARGE (they are a filter in front of the
+// exact test).
+struct SubBox { int x0, x1, y0, y1; };
+constexpr float kSubSlack = 1e-4f;
+__device__ __forceinline__ SubBox sub_box(const GridView& g, const BBoxF& bb, float ms) {
+    const float px = g.padx * ms + kSubSlack, py = g.pady * ms + kSubSlack;
+    SubBox s;
+    s.x0 = (int)floorf((bb.x0 - g.gx0) * g.inv_cw * (float)kSub - px);
+    s.x1 = (int)floorf((bb.x1 - g.gx0) * g.inv_cw * (float)kSub + px);
+    s.y0 = (int)floorf((bb.y0 - g.gy0) * g.inv_ch * (float)kSub - py);
+    s.y1 = (int)floorf((bb.y1 - g.gy0) * g.inv_ch * (float)kSub + py);
+    return s;
+}
+__device__ __forceinline__ uint32_t make_entry_i(const GridView& g, const SubBox& sb, int xx, int yy, uint32_t zq, int k) {
+    const int ox = xx * kSub, oy = yy * kSub;
+    const int a0 = min(max(sb.x0 - ox, 0), kSub - 1), a1 = min(max(sb.x1 - ox, 0), kSub - 1);
+    const int b0 = min(max(sb.y0 - oy, 0), kSub - 1), b1 = min(max(sb.y1 - oy, 0), kSub - 1);
     const uint32_t xm = (2u << a1) - (1u << a0), ym = (2u << b1) - (1u << b0);
     return (zq << (g.ib + 2 * kSub)) | (ym << (g.ib + kSub)) | (xm << g.ib) | (uint32_t)k;
 }
@@ -162,7 +227,7 @@ __device__ __forceinline__ uint32_t make_entry(const GridView& g, const BBoxF& b
 struct RasterAll { __device__ __forceinline__ bool operator()(int, int, int, int) const { return true; } };
 template <bool BBOX = false, class Fn, class Pre = RasterAll>
 __device__ __forceinline__ void raster_cells(float gx0, float gy0, float inv_cw, float inv_ch, int Rx, const Proj2& q, float ms, Fn fn,
-                                             Pre pre = Pre()) {
+                                             Pre pre = Pre(), unsigned long long* cnt = nullptr) {
     const float cw = __builtin_amdgcn_rcpf(inv_cw), ch = __builtin_amdgcn_rcpf(inv_ch);
     // slack: the projection's rounding (1e-7) and, above all, the error of a reported hit under the grazing rule
     const float mgx = ms * (kBoxFrac * cw + kSlopeAbs), mgy = ms * (kBoxFrac * ch + kSlopeAbs);
@@ -199,6 +264,9 @@ __device__ __forceinline__ void raster_cells(float gx0, float gy0, float inv_cw,
     for (int yy = cy0; yy <= cy1; ++yy) {
         float r0 = E0, r1 = E1, r2 = E2;
         for (int xx = cx0; xx <= cx1; ++xx) {
+#ifdef NLOS_FWD_STAMPS
+            if (cnt) { cnt[0] += 1; if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) cnt[1] += 1; }   // lane- and wave-iterations
+#endif
             if (thin | ((r0 >= 0.0f) & (r1 >= 0.0f) & (r2 >= 0.0f))) fn(xx, yy);
             r0 += ax0; r1 += ax1; r2 += ax2;
         }
@@ -214,8 +282,8 @@ __device__ __forceinline__ void raster_origin(const GridView& g, const Proj2& q,
     cy0 = cell_coord(fminf(fminf(q.ay, q.by), q.cy) - mgy, g.gy0, g.inv_ch, g.R);
 }
 template <class Fn, class Pre = RasterAll>
-__device__ __forceinline__ void raster_tri(const GridView& g, const Proj2& q, float ms, Fn fn, Pre pre = Pre()) {
-    raster_cells(g.gx0, g.gy0, g.inv_cw, g.inv_ch, g.R, q, ms, fn, pre);
+__device__ __forceinline__ void raster_tri(const GridView& g, const Proj2& q, float ms, Fn fn, Pre pre = Pre(), unsigned long long* cnt = nullptr) {
+    raster_cells(g.gx0, g.gy0, g.inv_cw, g.inv_ch, g.R, q, ms, fn, pre, cnt);
 }
 // the same on the coarse map of the depth bounds (one cell = 2 x 2 cells of the grid, R2 = (R + 1) / 2 per side): a
 // coarse cell is touched iff one of its four cells is (up to the slack), at a quarter of the cells
@@ -364,6 +432,9 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     int t_slot = 0;
     const long long c_start = t_prev, w_start = wall_clock64();   // shader-clock ticks vs the constant 100 MHz counter -> a.dbg[24], [25]
 #define FWD_STAMP() do { __syncthreads(); if (tid == 0 && a.dbg) { long long t_now = clock64(); atomicAdd((unsigned long long*)&a.dbg[t_slot], (unsigned long long)(t_now - t_prev)); ++t_slot; t_prev = t_now; } } while (0)
+    // round 6: trip counts of the build loops (lane- and wave-iterations) for the dynamic instruction histogram
+    unsigned long long c_cnt[2] = {0ull, 0ull}, c_cfw = 0ull, c_fill[2] = {0ull, 0ull}, c_ffw = 0ull;
+#define FWD_WAVE_FIRST() ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1)
 #else
 #define FWD_STAMP() do { } while (0)
 #endif
@@ -592,6 +663,10 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             for (int jl = tid; jl < Fl; jl += NT) {
 #endif
                 const int j = gid(jl);
+                diag_pad<NLOS_DIAG_PAD_COUNT>();
+#ifdef NLOS_FWD_STAMPS
+                if (attempt == 0 && FWD_WAVE_FIRST()) c_cfw += 1;
+#endif
                 const float4 q0 = a.sc.facerec[4 * j], q1 = a.sc.facerec[4 * j + 1], q2 = a.sc.facerec[4 * j + 2];
                 // the setup pass's margin scale of this triangle -- requested BEFORE the store below: loads and stores
                 // return in order (vmcnt), so a load behind the store would wait for the store's round trip to the L2
@@ -619,7 +694,11 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     big = cx1 - cx0 > 3 || cy1 - cy0 > 3;
                     reach = reachable(zn)(cx0, cx1, cy0, cy1);
                     return reach;
+#ifdef NLOS_FWD_STAMPS
+                }, c_cnt);
+#else
                 });
+#endif
                 pend_jl = jl; pend_cov = (uint16_t)(!reach ? 0u : big ? 0xFFFFu : cv);
             }
             if (pend_jl >= 0) g_cov[pend_jl] = pend_cov;
@@ -687,6 +766,9 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             // object), a mask of up to 4 x 4 cells, or a large bounding box that is rasterised again
             const uint32_t cov = g_cov[jl];
             const uint16_t msq = g_live[jl];
+#ifdef NLOS_FWD_STAMPS
+            if (FWD_WAVE_FIRST()) c_ffw += 1;
+#endif
             const bool counts_as_live = fill_buckets && ((s_mask[jl >> 6] >> (jl & 63)) & 1ull);
             if (cov == 0u && !counts_as_live) continue;
             uint32_t nmax = 0u;                              // longest list among the cells the triangle enters
@@ -702,12 +784,18 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 BBoxF bb;
                 bb.x0 = fminf(fminf(q.ax, q.bx), q.cx); bb.x1 = fmaxf(fmaxf(q.ax, q.bx), q.cx);
                 bb.y0 = fminf(fminf(q.ay, q.by), q.cy); bb.y1 = fmaxf(fmaxf(q.ay, q.by), q.cy);
+#ifndef NLOS_DIAG_FLOAT_ENTRY      // diagnostic builds only: the A/B of the integer entry
+                const SubBox sbx = sub_box(g, bb, ms);
+#define NLOS_MAKE_ENTRY(xx, yy) make_entry_i(g, sbx, xx, yy, zq, jl)
+#else
+#define NLOS_MAKE_ENTRY(xx, yy) make_entry(g, bb, xx, yy, zq, jl, ms)
+#endif
                 if (cov == 0xFFFFu) {
                     raster_tri(g, q, ms, [&](int xx, int yy) {
                         if (zn <= s_zc[(yy >> 1) * R2 + (xx >> 1)]) {
                             const int c = yy * R + xx;
                             uint32_t pos = atomicAdd(&s_cell[c], 1u);
-                            s_ent[pos] = make_entry(g, bb, xx, yy, zq, jl, ms);
+                            s_ent[pos] = NLOS_MAKE_ENTRY(xx, yy);
                             if (len_ok) nmax = max(nmax, (uint32_t)s_len8[c]);
                         }
                     }, reachable(zn));
@@ -715,11 +803,14 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     int bx0, by0;
                     raster_origin(g, q, ms, bx0, by0);
                     for (uint32_t m = cov; m; m &= m - 1u) {
+#ifdef NLOS_FWD_STAMPS
+                        c_fill[0] += 1; if (FWD_WAVE_FIRST()) c_fill[1] += 1;
+#endif
                         const int bit = __ffs((int)m) - 1;
                         const int xx = bx0 + (bit & 3), yy = by0 + (bit >> 2);
                         const int c = yy * R + xx;
                         uint32_t pos = atomicAdd(&s_cell[c], 1u);
-                        s_ent[pos] = make_entry(g, bb, xx, yy, zq, jl, ms);
+                        s_ent[pos] = NLOS_MAKE_ENTRY(xx, yy);
                         if (len_ok) nmax = max(nmax, (uint32_t)s_len8[c]);
                     }
                 }
@@ -830,6 +921,10 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     const double inv_spt = 1.0 / (double)spt;
 #ifdef NLOS_FWD_STAMPS
     unsigned long long c_rays = 0, c_pairs = 0, c_iters = 0, c_mt = 0, c_mtw = 0, c_hit = 0, c_occ = 0, c_tested = 0;   // diagnostic build only
+    unsigned long long c_items = 0, c_dfail = 0, c_push = 0;   // round 6: items, walked entries that fail the depth term, non-empty push slots
+    // round 6: of the pairs that reach the exact test, how many would survive a filter that knew the candidate's true projected
+    // coverage of the ray's sub-cell at 3 / 4 / 6 / 8 sub-cells per cell side, and the ideal one (the slope point itself, margin kSlopeAbs)
+    unsigned long long c_cov[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
     long long tg = 0, ts = 0, tx = 0, th = 0, tmark = 0;
 #define TMARK() (tmark = clock64())
 #define TACC(v) do { long long now_ = clock64(); v += now_ - tmark; tmark = now_; } while (0)
@@ -887,19 +982,45 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
         // (Claiming the next item and requesting its live-list entries one item ahead, so that ticket, entry and face
         // records are not three dependent round trips in front of every item's arithmetic, changes nothing: the kernel
         // waits for its VALU, not for these.  Measured, profiles/r03_ab_lookahead.log.)
+#ifndef NLOS_LOOKAHEAD
+#define NLOS_LOOKAHEAD 0
+#endif
+        // NLOS_LOOKAHEAD (round 6, re-measured on this kernel): the ticket and the live-list entry of the NEXT item are requested
+        // behind this item's face-record loads, so that ticket -> live list -> face record are two dependent round trips in front
+        // of an item's arithmetic instead of three (one scalar and one vector register live across the item).
+        auto slot_of = [&](uint32_t r, bool has) -> uint32_t { return has ? (magic_ok ? __umulhi(r, spt_magic) : r / (uint32_t)spt) : 0u; };
+        int b_next = NLOS_LOOKAHEAD ? wave_ticket(&s_ctl[0]) : 0;
+        int j_next = 0;
+        if (NLOS_LOOKAHEAD && b_next < n_items) {
+            const uint32_t r0 = ((uint32_t)b_next << 6) + (uint32_t)lane;
+            const uint32_t li0 = slot_of(r0, r0 < n_rays);
+            j_next = compact ? (int)g_live[li0] : (int)li0;
+        }
         for (;;) {
-            const int b = wave_ticket(&s_ctl[0]);
+            const int b = NLOS_LOOKAHEAD ? b_next : wave_ticket(&s_ctl[0]);
             if (b >= n_items) break;
             TMARK();
             const uint32_t r = ((uint32_t)b << 6) + (uint32_t)lane;
             bool has_ray = r < n_rays;
-            const uint32_t li = has_ray ? (magic_ok ? __umulhi(r, spt_magic) : r / (uint32_t)spt) : 0u;
+            const uint32_t li = slot_of(r, has_ray);
             const int s = has_ray ? (int)(r - li * (uint32_t)spt) : 0;
-            const int j = compact ? (int)g_live[li] : (int)li;              // index within this workgroup's face set
+            const int j = NLOS_LOOKAHEAD ? j_next : (compact ? (int)g_live[li] : (int)li);   // index within this workgroup's face set
             const int jg = gid(j);                                          // sorted-face index
             Face f;
             Tri tr;
             load_face_tri<FEAT>(a.sc, jg, f, tr);
+            if (NLOS_LOOKAHEAD) {
+                b_next = wave_ticket(&s_ctl[0]);
+                if (b_next < n_items) {
+                    const uint32_t r1 = ((uint32_t)b_next << 6) + (uint32_t)lane;
+                    const uint32_t li1 = slot_of(r1, r1 < n_rays);
+                    j_next = compact ? (int)g_live[li1] : (int)li1;
+                }
+            }
+            diag_pad<NLOS_DIAG_PAD_GEN>();
+#ifdef NLOS_FWD_STAMPS
+            if (lane == 0) c_items += 1;
+#endif
             if (visout) flush_pending();                                    // the previous item's words, behind this item's loads
             if (vitems) flush_item();
             if (!compact && has_ray) has_ray = !face_dark(f);               // (the block masks are gone: the queue reuses their LDS)
@@ -1079,6 +1200,38 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
 #ifdef NLOS_FWD_STAMPS
                             c_tested += 1;
                             if (hit_k) c_hit += 1;
+                            {
+                                const V3 k0 = tk.p0, k1 = tk.p0 - tk.e1, k2 = tk.p0 + tk.e2;
+                                const Proj2 qk = project_tri(o, k0, k1, k2);
+                                const float izd = 1.0f / od.z;
+                                const float mx = od.x * izd, my = od.y * izd;
+                                const float area = (qk.bx - qk.ax) * (qk.cy - qk.ay) - (qk.by - qk.ay) * (qk.cx - qk.ax);
+                                const float sgn = area < 0.0f ? -1.0f : 1.0f;
+                                const float A[3] = {-(qk.by - qk.ay) * sgn, -(qk.cy - qk.by) * sgn, -(qk.ay - qk.cy) * sgn};
+                                const float B[3] = {(qk.bx - qk.ax) * sgn, (qk.cx - qk.bx) * sgn, (qk.ax - qk.cx) * sgn};
+                                const float C[3] = {-(A[0] * qk.ax + B[0] * qk.ay), -(A[1] * qk.bx + B[1] * qk.by), -(A[2] * qk.cx + B[2] * qk.cy)};
+                                const float bx0 = fminf(fminf(qk.ax, qk.bx), qk.cx), bx1 = fmaxf(fmaxf(qk.ax, qk.bx), qk.cx);
+                                const float by0 = fminf(fminf(qk.ay, qk.by), qk.cy), by1 = fmaxf(fmaxf(qk.ay, qk.by), qk.cy);
+                                const float cwf = 1.0f / g.inv_cw, chf = 1.0f / g.inv_ch;
+                                const int subs[5] = {3, 4, 6, 8, 0};
+                                for (int si = 0; si < 5; ++si) {
+                                    float x0, x1, y0, y1;
+                                    if (subs[si] == 0) { x0 = x1 = mx; y0 = y1 = my; }
+                                    else {
+                                        const float S = (float)subs[si];
+                                        const float ux = (mx - g.gx0) * g.inv_cw, uy = (my - g.gy0) * g.inv_ch;
+                                        x0 = g.gx0 + floorf(ux * S) / S * cwf; x1 = x0 + cwf / S;
+                                        y0 = g.gy0 + floorf(uy * S) / S * chf; y1 = y0 + chf / S;
+                                    }
+                                    const float mg = kSlopeAbs + 0.02f * cwf / 4.0f;       // today's mask margin, in slope units
+                                    bool ov = bx1 + mg >= x0 && bx0 - mg <= x1 && by1 + mg >= y0 && by0 - mg <= y1;
+                                    for (int ei = 0; ei < 3 && ov; ++ei) {
+                                        const float ex = A[ei] > 0.0f ? x1 : x0, ey = B[ei] > 0.0f ? y1 : y0;
+                                        ov = A[ei] * ex + B[ei] * ey + C[ei] + (fabsf(A[ei]) + fabsf(B[ei])) * mg >= 0.0f;
+                                    }
+                                    if (ov || fabsf(area) < 1e-4f * cwf * chf) c_cov[si] += 1;
+                                }
+                            }
 #endif
                             if (hit_k)
                                 atomicOr(&wocc[owner >> 5], 1u << (owner & 31));
@@ -1138,6 +1291,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 // kScan entries per trip: the lockstep walk pays its loop overhead (any(), branch, counters) once per
                 // trip; lists average 24 entries, so wider trips waste more slots at the end (2: 2.49 ms, 4: 2.43 ms)
                 while (__any(e < e1)) {
+                    diag_pad<NLOS_DIAG_PAD_WALK>();
                     // every lane reads its next kScan words (finished lanes re-read the slots behind their list and
                     // fail the range term): no divergent region, the compare masks are combined on the scalar unit
                     const uint32_t rem = e < e1 ? e1 - e : 0u;
@@ -1155,6 +1309,11 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     if (lane == 0) c_iters += 1;
 #pragma unroll
                     for (int q = 0; q < kScan; ++q) if ((p[q] >> lane) & 1ull) c_mt += 1;
+#pragma unroll
+                    for (int q = 0; q < kScan; ++q) {
+                        if (grid_ray && (uint32_t)q < rem && (w[q] ^ jx) > rlim) c_dfail += 1;
+                        if (lane == 0 && p[q]) c_push += 1;
+                    }
 #endif
                     e += min((uint32_t)kScan, rem);
 #pragma unroll
@@ -1225,6 +1384,16 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
         atomicAdd((unsigned long long*)&a.dbg[18], c_hit);
         atomicAdd((unsigned long long*)&a.dbg[19], c_occ);
         atomicAdd((unsigned long long*)&a.dbg[6], c_tested);
+        atomicAdd((unsigned long long*)&a.dbg[7], c_push);
+        atomicAdd((unsigned long long*)&a.dbg[26], c_items);
+        atomicAdd((unsigned long long*)&a.dbg[27], c_cfw);
+        atomicAdd((unsigned long long*)&a.dbg[28], c_dfail);
+        atomicAdd((unsigned long long*)&a.dbg[29], c_cnt[0]);
+        atomicAdd((unsigned long long*)&a.dbg[30], c_cnt[1]);
+        atomicAdd((unsigned long long*)&a.dbg[31], c_fill[1]);
+        atomicAdd((unsigned long long*)&a.dbg[32], c_fill[0]);
+        atomicAdd((unsigned long long*)&a.dbg[33], c_ffw);
+        for (int si = 0; si < 5; ++si) atomicAdd((unsigned long long*)&a.dbg[34 + si], c_cov[si]);
         if (tid == 0) atomicAdd((unsigned long long*)&a.dbg[13], (unsigned long long)s_ctl[2]);
         if (lane == 0) {
             atomicAdd((unsigned long long*)&a.dbg[14], (unsigned long long)tg);

@@ -124,6 +124,12 @@ struct nlos_ctx {
     int tap_refine = -1, tap_sigma = -1; float tap_res = -1.0f; int tap_kind = -1;
     // host-pointer path staging
     DevBuf io[16];
+    // host-pointer drop-ins (round 6): a render stream and a copy stream of the context's own (non-blocking: a numpy call no
+    // longer stalls the legacy default stream or anybody's torch stream), and the events that order them --
+    // `host_p1`: pass 1 has finished (the rows are final: their download may start, behind pass 2);
+    // `host_up`: data / weight have arrived (pass 2 waits for it, pass 1 does not)
+    hipStream_t host_render = nullptr, host_copy = nullptr;
+    hipEvent_t host_p1 = nullptr, host_up = nullptr;
     // what the visibility cache currently describes
     struct VisKey { int L = -1, F = -1, V = -1, spt = -1; long long off = -1; int stride = 1; uint64_t seed = 0; float lb = 0, ub = 0;
                     int feat = -1; int64_t mesh_gen = -1; } vis_key;
@@ -285,7 +291,7 @@ int ensure_bvh(nlos_ctx* c, const float* V, int nV, const int32_t* F, int nF, bo
     rc |= c->parent.ensure(sizeof(int) * n_nodes);
     rc |= c->arrive.ensure(sizeof(int) * (size_t)nF);
     rc |= c->box.ensure(sizeof(float) * (6 * n_nodes + 8));      // + the box padding handed to k_build_refit
-    rc |= c->status.ensure(sizeof(int) * 64);
+    rc |= c->status.ensure(sizeof(int) * 128);      // (64 ints of status + scratch; the diagnostic builds' 40 counters)
     rc |= c->nodes.ensure(sizeof(float4) * 2 * n_nodes);
     rc |= c->tris.ensure(sizeof(float4) * 4 * (size_t)nF);
     rc |= c->facerec.ensure(sizeof(float4) * 4 * (size_t)nF);
@@ -411,6 +417,10 @@ void nlos_ctx_destroy(nlos_ctx* c) {
     for (hipEvent_t& e : c->ring) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
     if (c->status_ev) { hipError_t r = hipEventDestroy(c->status_ev); (void)r; }
     if (c->h_status) { hipError_t r = hipHostFree(c->h_status); (void)r; }
+    if (c->host_p1) { hipError_t r = hipEventDestroy(c->host_p1); (void)r; }
+    if (c->host_up) { hipError_t r = hipEventDestroy(c->host_up); (void)r; }
+    if (c->host_render) { hipError_t r = hipStreamDestroy(c->host_render); (void)r; }
+    if (c->host_copy) { hipError_t r = hipStreamDestroy(c->host_copy); (void)r; }
     delete c;
 }
 
@@ -500,6 +510,16 @@ static int check_window_and_taps(const nlos_render_args* a) {
         return fail(NLOS_ERR_ARG, "nlos_render: temporal kernel longer than 2048 taps (4 * refine_scale * sigma_bin + 1, or jitter_length)");
     return NLOS_OK;
 }
+
+}  // extern "C" (re-opened below)
+namespace {
+// Host drop-ins only (section 1): called by nlos_render on its stream between pass 1 and the first kernel that reads
+// `data` / `weight` -- the host entry uploads those two matrices THERE, on its copy stream, while pass 1 runs, and starts
+// the download of the finished rows behind pass 2.  Null for every other caller.
+struct AfterPass1 { int (*fn)(void* self, hipStream_t st); void* self; };
+thread_local AfterPass1* tl_after_pass1 = nullptr;
+}  // namespace
+extern "C" {
 
 int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     if (c && a && a->n_sensors > 0) return render_product(c, a, stream);
@@ -678,8 +698,8 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         fa.tile_cap = (int)tcap;
     }
 #ifdef NLOS_FWD_STAMPS
-    HIP_TRY(hipMemsetAsync(c->status.p, 0, 64 * sizeof(int), st));
-    fa.dbg = c->status.as<long long>();     // 8 x int64 (diagnostic build only)
+    HIP_TRY(hipMemsetAsync(c->status.p, 0, 48 * sizeof(long long), st));
+    fa.dbg = c->status.as<long long>();     // 40 x int64 (diagnostic build only)
 #endif
     fa.rows = nullptr;
     fa.vis2 = nullptr;
@@ -803,7 +823,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     }
 #ifdef NLOS_FWD_STAMPS
     {
-        long long h[26];
+        long long h[48];
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h, c->status.p, sizeof(h), hipMemcpyDeviceToHost));
         double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5]);
@@ -819,6 +839,13 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
                      (double)h[11] / (double)(h[8] ? h[8] : 1), (double)h[12] / rw);
         std::fprintf(stderr, "[fwd occlusion] rays found occluded %.1f%% | exact tests %lld, of which an occluder %.1f%%\n",
                      100.0 * (double)h[19] / (double)(h[8] ? h[8] : 1), h[6], 100.0 * (double)h[18] / (double)(h[6] ? h[6] : 1));
+        // round 6: trip counts for the dynamic instruction histogram (tools/dynamic_histogram.py) and the depth-order bound
+        std::fprintf(stderr, "[fwd trips] items %lld walk_trips %lld push_slots %lld exact_rounds %lld count_face_waves %lld count_cell_lane_it %lld count_cell_wave_it %lld "
+                             "fill_face_waves %lld fill_entry_lane_it %lld fill_entry_wave_it %lld | walked entries %lld of which fail the depth term %lld (%.1f%%)\n",
+                     h[26], h[10], h[7], h[12], h[27], h[29], h[30], h[33], h[32], h[31], h[9], h[28], 100.0 * (double)h[28] / (double)(h[9] ? h[9] : 1));
+        std::fprintf(stderr, "[fwd pair filter bound] exact tests %lld | would survive true sub-cell coverage at 3 / 4 / 6 / 8 per side: %.1f%% %.1f%% %.1f%% %.1f%% | ideal point test %.1f%%\n",
+                     h[6], 100.0 * h[34] / (double)(h[6] ? h[6] : 1), 100.0 * h[35] / (double)(h[6] ? h[6] : 1), 100.0 * h[36] / (double)(h[6] ? h[6] : 1),
+                     100.0 * h[37] / (double)(h[6] ? h[6] : 1), 100.0 * h[38] / (double)(h[6] ? h[6] : 1));
         if (h[25] > 0) {
             // s_memtime counts shader-clock cycles, s_memrealtime the constant 100 MHz reference: their ratio over the
             // workgroups' lifetimes is the engine clock the forward kernel ran at (tools/issue_model.py uses it)
@@ -868,6 +895,12 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         nlos::launch_smooth(sm, st);
     }
     mark(c, 2, st);
+    if (tl_after_pass1) {
+        AfterPass1* h = tl_after_pass1;
+        tl_after_pass1 = nullptr;                  // once per host call
+        rc = h->fn(h->self, st);
+        if (rc) return rc;
+    }
 
     // ---- residual + pathlengths -----------------------------------------------------
     if (mode == NLOS_MODE_TRANSIENT || (mode == NLOS_MODE_VERTEX_GRADIENT)) {
@@ -1367,6 +1400,88 @@ struct HostCall {
         downloads.push_back({host, {b.p, count * sizeof(T)}});
         return b.as<T>();
     }
+    // ---- pipelined form (host_render, round 6) ------------------------------------------------------------------
+    // Large inputs that pass 1 does not read (data, weight) get their device buffer now and their bytes LATER: after_pass1()
+    // -- called by nlos_render between the passes -- copies them on the context's copy stream while pass 1 runs on the
+    // render stream, and makes the render stream wait for their arrival.  The rows (transient) are final when pass 1 is,
+    // so their download runs on the copy stream behind pass 2.  Small arrays keep the synchronous copies.
+    struct Deferred { void* dev; const void* host; size_t bytes; };
+    std::vector<Deferred> deferred;
+    void* early_host = nullptr; void* early_dev = nullptr; size_t early_bytes = 0;   // the rows: downloaded behind pass 2
+    bool hook_ran = false;
+    template <class T>
+    T* up_deferred(const T* host, size_t count) {
+        if (rc || !host || count == 0) return nullptr;
+        DevBuf& b = c->io[slot++];
+        rc = b.ensure(count * sizeof(T));
+        if (rc) return nullptr;
+        deferred.push_back({b.p, host, count * sizeof(T)});
+        return b.as<T>();
+    }
+    template <class T>
+    T* out_early(T* host, size_t count) {
+        if (rc || !host || count == 0) return nullptr;
+        DevBuf& b = c->io[slot++];
+        rc = b.ensure(count * sizeof(T));
+        if (rc) return nullptr;
+        early_host = host; early_dev = b.p; early_bytes = count * sizeof(T);
+        return b.as<T>();
+    }
+    int ensure_streams() {
+        if (!c->host_render) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->host_render, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&c->host_copy, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&c->host_p1, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->host_up, hipEventDisableTiming));
+        }
+        return NLOS_OK;
+    }
+    int run_deferred(hipStream_t render) {
+        // (pageable sources: the call returns when the bytes are staged / on the wire, the GPU keeps running pass 1 meanwhile;
+        // 55 GB/s on the round-6 box, tools/host_copy_probe.hip)
+        for (auto& d : deferred) HIP_TRY(hipMemcpyAsync(d.dev, d.host, d.bytes, hipMemcpyHostToDevice, c->host_copy));
+        if (!deferred.empty()) {
+            HIP_TRY(hipEventRecord(c->host_up, c->host_copy));
+            HIP_TRY(hipStreamWaitEvent(render, c->host_up, 0));
+        }
+        deferred.clear();
+        return NLOS_OK;
+    }
+    static int after_pass1_thunk(void* self, hipStream_t st) {
+        HostCall* h = static_cast<HostCall*>(self);
+        h->hook_ran = true;
+        HIP_TRY(hipEventRecord(h->c->host_p1, st));
+        return h->run_deferred(st);
+    }
+    // after nlos_render has returned (everything is enqueued): the rows come down behind pass 2, the small outputs behind the
+    // render stream; no device-wide synchronisation
+    int finish_pipelined(hipStream_t render) {
+        if (rc) return rc;
+        hipError_t e;
+        if (early_host) {
+            if (hook_ran) e = hipStreamWaitEvent(c->host_copy, c->host_p1, 0);
+            else e = hipStreamSynchronize(render);          // (a path that did not pass the hook: after everything)
+            if (e == hipSuccess) e = hipMemcpyAsync(early_host, early_dev, early_bytes, hipMemcpyDeviceToHost, c->host_copy);
+            if (e != hipSuccess) return fail(NLOS_ERR_HIP, std::string("download of the rows: ") + hipGetErrorString(e));
+        }
+        e = hipStreamSynchronize(render);
+        if (e != hipSuccess) return fail(NLOS_ERR_HIP, std::string("hipStreamSynchronize(render): ") + hipGetErrorString(e));
+        for (auto& d : downloads) {
+            e = hipMemcpyAsync(d.first, d.second.first, d.second.second, hipMemcpyDeviceToHost, render);
+            if (e != hipSuccess) return fail(NLOS_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
+        }
+        int st[4] = {0, 0, 0, 0};
+        e = hipMemcpyAsync(st, c->status.p, sizeof(st), hipMemcpyDeviceToHost, render);
+        if (e == hipSuccess) e = hipStreamSynchronize(render);
+        hipError_t e2 = hipStreamSynchronize(c->host_copy);
+        if (e2 != hipSuccess) return fail(NLOS_ERR_HIP, std::string("hipStreamSynchronize(copy): ") + hipGetErrorString(e2));
+        c->status_pending = false;
+        if (e == hipSuccess && (st[0] & 1)) {
+            c->status_clear = true;
+            return fail(NLOS_ERR_ARG, "face index out of range [0, numVertices)");
+        }
+        return NLOS_OK;
+    }
     int finish() {
         if (rc) return rc;
         hipError_t e = hipDeviceSynchronize();
@@ -1415,6 +1530,11 @@ int host_render(const HostRender& h) {
     DeviceGuard guard(c->device);
     HostCall hc;
     hc.c = c;
+    rc = hc.ensure_streams();
+    if (rc) return rc;
+    // data / weight are first read after pass 1 (residual / pass 2): their upload rides behind it (HostCall, pipelined form);
+    // the product entry consumes them inside its own sequence of launches: uploaded up front there
+    const bool defer = h.n_sensors == 0;
     const int T = h.mode == NLOS_MODE_INTENSITY ? 0 : nlos_num_bins(h.lb, h.ub, h.res);
     nlos_render_args a;
     nlos_render_args_init(&a);
@@ -1438,9 +1558,9 @@ int host_render(const HostRender& h) {
     a.lower_bound = h.lb; a.upper_bound = h.ub; a.resolution = h.res;
     a.refine_scale = h.refine; a.sigma_bin = h.sigma_bin;
     a.seed = g_default_seed;
-    a.data = hc.up(h.data, n_meas * T);
-    a.weight = hc.up(h.weight, n_meas * T);
-    a.transient = hc.inout(h.transient, n_meas * T, false);
+    a.data = defer ? hc.up_deferred(h.data, n_meas * T) : hc.up(h.data, n_meas * T);
+    a.weight = defer ? hc.up_deferred(h.weight, n_meas * T) : hc.up(h.weight, n_meas * T);
+    a.transient = hc.out_early(h.transient, n_meas * T);
     a.pathlengths = hc.inout(h.pathlengths, (size_t)T, false);
     if (h.mode == NLOS_MODE_VERTEX_GRADIENT) a.gradient = hc.inout(h.gradient, 3 * (size_t)T, true);
     else a.gradient = hc.inout(h.gradient, 3 * (size_t)h.V, h.mode != NLOS_MODE_GRADIENT_V1);
@@ -1457,9 +1577,21 @@ int host_render(const HostRender& h) {
         if (h.scalar) *h.scalar = 0.0;
         return NLOS_OK;
     }
-    rc = nlos_render(c, &a, nullptr);
-    if (rc) return rc;
-    return hc.finish();
+    AfterPass1 hook{&HostCall::after_pass1_thunk, &hc};
+    tl_after_pass1 = defer ? &hook : nullptr;
+    rc = nlos_render(c, &a, c->host_render);
+    tl_after_pass1 = nullptr;
+    if (rc) {
+        // nothing may still be reading the staging buffers or writing host memory when the caller sees the error
+        hipError_t e1 = hipStreamSynchronize(c->host_render), e2 = hipStreamSynchronize(c->host_copy);
+        (void)e1; (void)e2;
+        return rc;
+    }
+    if (!hc.hook_ran && !hc.deferred.empty()) {
+        // cannot happen on the paths above (every non-product render passes the hook); never leave inputs behind silently
+        return fail(NLOS_ERR_ARG, "host drop-in: deferred inputs were not consumed");
+    }
+    return hc.finish_pipelined(c->host_render);
 }
 
 }  // namespace
