@@ -47,6 +47,25 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 PARITY_TOL = {"transient_rel_l2": 1e-5, "transient_max_abs_over_max": 1e-6, "gradient_rel_l2": 1e-4}
 
 
+# BASELINE.json's other configurations on SURVEY 8(d)'s inputs, plus the shape every experiment script of the reference runs
+# (`--config`, round 6): side measurements, each gated against the oracle like the metric line and carrying its own roofline.
+CONFIGS = {
+    "metric": {},
+    # cfg 2 / 3: exp_bunny mesh, 32x32 confocal, 512 bins; forward only / forward + gradient
+    "2": dict(grid=32, forward_only=True),
+    "3": dict(grid=32),
+    # cfg 4: exp_mannequin mesh, 64x64 wall points on +-0.35 m, 1024 bins of 2.4 mm from 0 -- confocal on the reference's own
+    # measurement (exp_mannequin/transient.mat: tests/golden/mannequin_measurement.npz), and its non-confocal pairs
+    "4": dict(mesh="mannequin", bins=1024, half=0.35, lb=0.0, res=2.4e-3, measurement=True),
+    "4pairs": dict(mesh="mannequin", bins=1024, half=0.35, lb=0.0, res=2.4e-3, non_confocal=True),
+    # cfg 5: GGX branch (alpha 0.3) + Poisson-noised measured transient, 64x64x1024
+    "5": dict(bins=1024, alpha=0.3, poisson=True),
+    # the shape of the reference's experiment scripts: 64x64 sources per call, 1200 bins x 1.2 mm from 0, refine 10, sigma_bin 1
+    # (exp_bunny/test.py:33-44,62-66, exp_ggx/test1.py:21-22)
+    "exp": dict(bins=1200, lb=0.0, res=1.2e-3),
+}
+
+
 def grid_sources(nx, ny, half):
     gx = np.linspace(-half, half, nx)
     gy = np.linspace(-half, half, ny)
@@ -89,7 +108,7 @@ def counters_of_this_build(pmc, kernel, comparable, L, F):
 # CPU side of rank 0: the oracle as parity checker and as the reported baseline (never the product)
 # ------------------------------------------------------------------------------------------------
 def _oracle_block(v, f, origin, normal, lb, ub, res, num_sample, data_rows, n, threads, source_offset=0,
-                  forward_only=False, sensor=None, sensor_normal=None, source_stride=1):
+                  forward_only=False, sensor=None, sensor_normal=None, source_stride=1, ggx_alpha=None):
     """Rows and vertex gradient of the first n sources of a block by the CPU oracle (total_sources = n; RNG keys
     of the block's global source indices); returns (transient, gradient or None, seconds).  The same call for every
     workload the bench can time: confocal forward + gradient, forward only, non-confocal pairs, any mesh."""
@@ -99,6 +118,8 @@ def _oracle_block(v, f, origin, normal, lb, ub, res, num_sample, data_rows, n, t
     d = np.ascontiguousarray(data_rows[:n])
     w = np.ones_like(d)
     kw = dict(accel=1, threads=threads, seed=0, source_offset=int(source_offset), source_stride=int(source_stride))
+    if ggx_alpha is not None:
+        kw["ggx_alpha"] = float(ggx_alpha)
     t0 = time.perf_counter()
     if sensor is not None:
         tr, g, _ = oracle.render_nonconfocal(o, nn, np.ascontiguousarray(sensor[:n]), np.ascontiguousarray(sensor_normal[:n]),
@@ -240,6 +261,10 @@ def workload_config(args, g, T, F, V, spt, L_total, world):
     return {
         "workload": ("ONE RANK'S SHARE (rank %d of %d) of the strong split, side measurement, not the metric: " % (args.as_rank, args.of)
                      if args.of > 1 else "") +
+                    ("BASELINE config %s (side measurement, not the metric): " % args.config if args.config != "metric" else "") +
+                    ("GGX alpha %.2f, Poisson-noised measurement, " % args.alpha if args.alpha is not None else "") +
+                    ("the reference's measured photon counts and wall points (exp_mannequin/transient.mat), " if args.measurement else "") +
+                    ("window [%g, %g) m in %g mm bins, " % (args.lb, args.lb + T * args.res_m, 1e3 * args.res_m) if args.res_m is not None else "") +
                     ("NON-CONFOCAL pairs (row N side measurement, not the metric) " if args.non_confocal else "") +
                     ("SUBDIVIDED mesh x4^%d (side measurement, not the metric) " % args.subdivide if args.subdivide else "") +
                     ("RE-DECIMATED mesh (side measurement, not the metric) " if args.faces else "") +
@@ -269,8 +294,9 @@ def parse_args(argv=None):
     ap.add_argument("--prewarm-seconds", type=float, default=0.5,
                     help="untimed steps before the W warm-up steps, for at least this long: the GPU idles while the CPU oracle "
                          "runs the parity gate and its clocks take tens of milliseconds to come back (0 = skip)")
-    ap.add_argument("--sustain-seconds", type=float, default=2.0,
-                    help="after the timed steps: a loop of at least this long, reported as sustained_ms_per_step (0 = skip)")
+    ap.add_argument("--sustain-seconds", type=float, default=6.0,
+                    help="after the timed steps: a loop of at least this long, reported as sustained_ms_per_step (0 = skip; "
+                         "6 s by default so that a 5-s activity sampler always sees the GPU busy)")
     ap.add_argument("--diagnostic-no-gate", action="store_true",
                     help="kernel-variant experiments (tools/ab_pmc.sh builds variants whose results are deliberately wrong): a "
                          "failing parity gate does not stop the run, but NO JSON line is printed -- per-kernel ms go to stderr, exit code 3")
@@ -294,6 +320,12 @@ def parse_args(argv=None):
     ap.add_argument("--share-steps", type=int, default=10,
                     help="N = 1, metric workload: after the timed steps, time every rank's block of the 2-, 4- and 8-way strong "
                          "split for this many steps each and report them as `strong_share` (0 = skip)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="metric",
+                    help="which BASELINE.json configuration to time (default: the metric's).  2 / 3: bunny 32x32x512 forward / "
+                         "forward+gradient; 4: mannequin 64x64x1024 on the reference's own measurement (+-0.35 m, 2.4 mm bins "
+                         "from 0); 4pairs: its non-confocal pairs; 5: GGX alpha 0.3, 64x64x1024, Poisson-noised data; exp: the "
+                         "reference's experiment shape, 64x64 x 1200 bins of 1.2 mm from 0.  Everything but `metric` is a side "
+                         "measurement with its own parity gate and roofline")
     ap.add_argument("--dropin-steps", type=int, default=20,
                     help="N = 1, metric workload: after the timed steps, time the same step through the reference-shaped host "
                          "entry (renderer.renderStreamedGradient on numpy arrays: what main.py / exp_bunny/test.py call) and "
@@ -302,7 +334,13 @@ def parse_args(argv=None):
     ap.add_argument("--non-confocal", action="store_true",
                     help="row N side measurement (not the metric): every source becomes a (laser, sensor) pair, "
                          "sensor = laser + (0.05, -0.03, 0)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    preset = CONFIGS[args.config]
+    args.half, args.lb, args.res_m, args.alpha = 0.25, None, None, None
+    args.measurement = args.poisson = False
+    for k, val in preset.items():
+        setattr(args, {"res": "res_m"}.get(k, k), val)
+    return args
 
 
 # ------------------------------------------------------------------------------------------------
@@ -404,14 +442,33 @@ def run_rank(args, backend):
         v_np, f_np = np.ascontiguousarray(v_np, np.float32), np.ascontiguousarray(f_np, np.int32)
     F, V = f_np.shape[0], v_np.shape[0]
     T = args.bins
-    lb, ub, res = 0.625, 1.625, 1.0 / T          # exact in fp32 for T = 512 / 1024
+    if args.res_m is None:
+        lb, ub, res = 0.625, 1.625, 1.0 / T      # exact in fp32 for T = 512 / 1024
+    else:
+        # a window given by its bin width: ub the way the reference's scripts form it (max_distance_bin * distance_resolution,
+        # exp_bunny/rendering.py:258), falling back to the fp32 product where that rounds to one bin more
+        from nlos_surface_optimization_amd import _lib as _nl
+        lb, res = float(args.lb), float(args.res_m)
+        ub = lb + T * res
+        if _nl.num_bins(lb, ub, res) != T:
+            ub = float(np.float32(lb) + np.float32(T) * np.float32(res))
+        if _nl.num_bins(lb, ub, res) != T:
+            raise SystemExit("bench.py: the window of --config %s does not give %d bins" % (args.config, T))
     spt = 1 + (args.num_sample - 1) // F
 
     g = args.grid
     if args.scaling == "weak":
-        origin_np, normal_np = grid_sources(g, g * world, 0.25)    # 64 x 64N grid, one 64x64 block per rank
+        origin_np, normal_np = grid_sources(g, g * world, args.half)    # 64 x 64N grid, one 64x64 block per rank
     else:
-        origin_np, normal_np = grid_sources(g, g, 0.25)            # one 64x64 grid, split over the ranks
+        origin_np, normal_np = grid_sources(g, g, args.half)            # one 64x64 grid, split over the ranks
+    meas = None
+    if args.measurement:
+        # cfg 4 on its real inputs: the reference's wall points and photon counts (tests/golden/mannequin_measurement.npz)
+        meas = np.load(os.path.join(ROOT, "tests", "golden", "mannequin_measurement.npz"))
+        origin_np = np.ascontiguousarray(meas["lighting"], np.float32)
+        normal_np = np.ascontiguousarray(np.tile(np.array([0, 0, 1], np.float32), (origin_np.shape[0], 1)))
+        if world != 1 or args.scaling == "weak":
+            raise SystemExit("bench.py: --config 4 (the measured wall points) is a one-GPU side measurement")
     L_total = origin_np.shape[0]
     partition = args.partition if args.scaling == "strong" else "contiguous"    # (weak: one whole grid per rank)
     own, lo, stride = ndist.shard_slice(L_total, rank, world, partition)
@@ -431,8 +488,19 @@ def run_rank(args, backend):
     # synthetic measurement: transient of a slightly displaced copy of the mesh, weight == 1
     rs = np.random.RandomState(0)
     v_gt = torch.from_numpy((v_np + 0.002 * rs.standard_normal(v_np.shape)).astype(np.float32)).to(dev)
-    data, _ = r.render_transient(origin, normal, v_gt, faces, args.num_sample, lb, ub, res,
-                                 total_sources=L_total, seed=1, **keys)
+    akw = {} if args.alpha is None else {"alpha": float(args.alpha)}          # GGX branch (cfg 5)
+    if meas is not None:
+        data = torch.from_numpy(np.ascontiguousarray(meas["counts"], np.float64)[own]).to(dev)
+    elif args.poisson:
+        # exp_noise/noise/addNoiseExample.m:9 -- Poisson-noised clean transient + background, numpy default_rng(0)
+        clean, _ = r.render_transient(origin, normal, verts, faces, args.num_sample, lb, ub, res, total_sources=L_total, **keys, **akw)
+        clean = clean.cpu().numpy()
+        rng = np.random.default_rng(0)
+        cs = 2e4 / np.maximum(clean.sum(axis=1, keepdims=True), 1e-300)
+        data = torch.from_numpy(np.ascontiguousarray(rng.poisson(cs * clean) / cs + rng.poisson(0.05, clean.shape) / cs)).to(dev)
+    else:
+        data, _ = r.render_transient(origin, normal, v_gt, faces, args.num_sample, lb, ub, res,
+                                     total_sources=L_total, seed=1, **keys, **akw)
     weight = torch.ones_like(data)
     grad = torch.zeros((V, 3), dtype=torch.float64, device=dev)
     nc = {}
@@ -442,11 +510,14 @@ def run_rank(args, backend):
     # ---- parity gate: EVERY rank checks the first sources of ITS block of the very workload that is timed (confocal or
     # pairs, forward-only or with the gradient, whatever the mesh); the flags are MIN-all-reduced, so a result line
     # means every GPU passed.  On rank 0 at N = 1 the CPU leg doubles as the reported baseline. ----
-    plain = not (args.forward_only or args.non_confocal or args.subdivide or args.faces or args.of > 1) and args.mesh == "bunny_5k"
+    plain = (not (args.forward_only or args.non_confocal or args.subdivide or args.faces or args.of > 1) and args.mesh == "bunny_5k"
+             and args.config == "metric" and args.grid == 64 and args.bins == 512)
     parity, cpu_base = None, None
     budget = 15.0 if (world == 1 and plain and not args.no_cpu_baseline) else 0.0
     data_np = data.cpu().numpy()
     wk = {"forward_only": bool(args.forward_only)}
+    if args.alpha is not None:
+        wk["ggx_alpha"] = float(args.alpha)
     if args.non_confocal:
         wk.update(sensor=nc["sensor"].cpu().numpy(), sensor_normal=nc["sensor_normal"].cpu().numpy())
     n_ref, t_ref, g_ref, cpu_base = cpu_reference(v_np, f_np, origin_np, normal_np, lb, ub, res,
@@ -457,13 +528,13 @@ def run_rank(args, backend):
         ncb = {k: t[:n].contiguous() for k, t in nc.items()}
         if args.forward_only:
             tb, _ = r.render_transient(origin[:n].contiguous(), normal[:n].contiguous(), verts, faces, args.num_sample,
-                                       lb, ub, res, total_sources=n, **keys, **ncb)
+                                       lb, ub, res, total_sources=n, **keys, **ncb, **akw)
             return tb.cpu().numpy(), None
         gb = torch.zeros((V, 3), dtype=torch.float64, device=dev)
         tb, gb, _ = r.render_gradient(origin[:n].contiguous(), normal[:n].contiguous(), verts, faces,
                                       args.num_sample, lb, ub, res, data=data[:n].contiguous(),
                                       weight=weight[:n].contiguous(), refine_scale=10, sigma_bin=1,
-                                      testing_flag=1, loss_flag=0, gradient=gb, total_sources=n, **keys, **ncb)
+                                      testing_flag=1, loss_flag=0, gradient=gb, total_sources=n, **keys, **ncb, **akw)
         return tb.cpu().numpy(), gb.cpu().numpy()
 
     parity = parity_gate(render_block, n_ref, t_ref, g_ref)
@@ -492,11 +563,11 @@ def run_rank(args, backend):
     def step():
         if args.forward_only:
             r.render_transient(origin, normal, verts, faces, args.num_sample, lb, ub, res,
-                               total_sources=L_total, **keys, **nc)
+                               total_sources=L_total, **keys, **nc, **akw)
         else:
             r.render_gradient(origin, normal, verts, faces, args.num_sample, lb, ub, res, data=data,
                               weight=weight, refine_scale=10, sigma_bin=1, testing_flag=1, loss_flag=0,
-                              gradient=grad, zero_gradient=True, total_sources=L_total, **keys, **nc)
+                              gradient=grad, zero_gradient=True, total_sources=L_total, **keys, **nc, **akw)
             if direct is not None:
                 direct.all_reduce_sum_(grad)
             elif world > 1:
@@ -629,7 +700,9 @@ def run_rank(args, backend):
             # schema 5 (round 5): + rays_traced_per_step / accepted_per_step / traced_rays_per_s, roofline.step_model,
             # roofline.valu_issue_frac, roofline.pass2, strong_share[partition][N].per_rank_kernel_ms.  Schema 4 (round 4):
             # strong_share nested as [partition][N] (default partition strided), as_rank.sources a count.
-            "schema": 5,
+            # schema 6 (round 6): + dropin_ms_per_step / autograd_ms_per_step (+ `dropin`, `autograd`), roofline.frac_on_traced_rays,
+            # roofline.issue.in_situ (measured marginal issue costs), --config side lines, sustained loop >= 6 s by default.
+            "schema": 6,
             "metric": METRIC,
             "value": samples_per_step * args.steps / elapsed,
             "unit": "samples/s",
@@ -693,6 +766,10 @@ def run_rank(args, backend):
                 "algorithmic_bytes_per_sample": per_sample,
                 "kernel_ms": {n: float(x) for n, x in zip(names, kt)},
             }
+            if rays[0] >= 0 and world == 1:
+                # the same contract figure priced on the rays pass 1 really traces (the samples of faces seen from behind are
+                # dropped before sampling: `frac` counts them, this does not)
+                roof["frac_on_traced_rays"] = per_sample * rays[0] / (kt[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS
             if traffic:
                 roof["hbm_measured_GBps"] = traffic / (kt[dom] * 1e-3) / 1e9
                 roof["hbm_measured_frac"] = roof["hbm_measured_GBps"] / HBM_PEAK_GBS

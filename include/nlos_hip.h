@@ -32,6 +32,10 @@ const char *nlos_last_error(void);
 int nlos_device_count(void);
 /* library version: major*10000 + minor*100 + patch */
 int nlos_version(void);
+/* Every behaviour-changing environment switch of the library with the value this process read (once, at first use) and its
+ * default in parentheses, one "NAME=value (default)" per line.  Writes at most `cap` bytes (NUL-terminated) into `buf`
+ * (which may be NULL) and returns the length of the full text. */
+int nlos_env_report(char *buf, int cap);
 
 /* ------------------------------------------------------------------------
  * Section 1 -- host-pointer drop-ins (reference signatures)

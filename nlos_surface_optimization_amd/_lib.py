@@ -122,6 +122,7 @@ SYMBOLS = {
     "nlos_last_error": (ctypes.c_char_p, []),
     "nlos_device_count": (_I, []),
     "nlos_version": (_I, []),
+    "nlos_env_report": (_I, [ctypes.c_char_p, _I]),
     "nlos_streamed_render_transient": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _I, _I]),
     "nlos_streamed_render_intensity": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _I, _F, _F, _P]),
     "nlos_streamed_render_gradient": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _I, _I, _I, _I]),
@@ -261,6 +262,17 @@ def check(rc, what=""):
 
 def device_count():
     return int(lib().nlos_device_count())
+
+
+def env_report():
+    """The library's environment switches as {name: value-as-read} (nlos_env_report)."""
+    buf = ctypes.create_string_buffer(2048)
+    lib().nlos_env_report(buf, 2048)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        k, _, rest = line.partition("=")
+        out[k] = rest.split(" ")[0]
+    return out
 
 
 def num_bins(lb, ub, res):

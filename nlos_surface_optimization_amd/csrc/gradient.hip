@@ -703,8 +703,13 @@ void launch_gradient(const GradientArgs& a_in, hipStream_t stream) {
     if (per_cu < 1) per_cu = 1;
     int grid = device_cu_count() * per_cu;
     if (grid > a.src.L) grid = a.src.L;
+    // few sources (a rank's share of a strong split): a workgroup that owns ONE source pays the zeroing and the flush of its
+    // 3V-double accumulator for that one source; NLOS_GRAD_MIN_SOURCES > 1 hands every workgroup at least that many
+    // (fewer, longer workgroups).  Measured in round 6 (profiles/r06_ab_grad_min_sources.log); default from there.
+    const int min_src = env_switches().grad_min_sources;
+    if (a.lds_grad && min_src > 1 && a.src.L / min_src >= 1 && grid > a.src.L / min_src) grid = a.src.L / min_src;
     // a single workgroup per CU: give it the sixteen waves two workgroups would have had
-    static const int wide_ok = [] { const char* e = std::getenv("NLOS_GRAD_WIDE"); return e ? std::atoi(e) : 1; }();
+    const int wide_ok = env_switches().grad_wide;
     const bool wide = per_cu == 1 && a.mode == 0 && wide_ok;
     switch (feat_of(a.sc, a.sp)) {
         case 0: gradient_launch<0>(a, grid, lds, stream, wide); break;

@@ -378,6 +378,19 @@ const char* nlos_last_error(void) { return g_err.c_str(); }
 
 int nlos_version(void) { return 100; }
 
+int nlos_env_report(char* buf, int cap) {
+    const nlos::EnvSwitches& e = nlos::env_switches();
+    char tmp[1024];
+    const int n = std::snprintf(tmp, sizeof(tmp),
+        "NLOS_TILE_THRESHOLD=%d (6200)\nNLOS_LAZY_TREE=%d (1)\nNLOS_FUSE_RESIDUAL=%d (1)\nNLOS_TILE_TRIS=%d (3000)\n"
+        "NLOS_TILE_SCRATCH_MAX=%llu (34359738368)\nNLOS_VIS_ITEMS=%d (1)\nNLOS_GEO_CACHE=%d (1)\nNLOS_GEO_CACHE_MAX_GB=%g (-1)\n"
+        "NLOS_ROW_LDS_MAX=%zu (10240)\nNLOS_GRAD_WIDE=%d (1)\nNLOS_GRAD_MIN_SOURCES=%d (1)\n",
+        e.tile_threshold, (int)e.lazy_tree, (int)e.fuse_residual, e.tile_tris, e.tile_scratch_max, (int)e.vis_items, (int)e.geo_cache,
+        e.geo_cache_max_gb, e.row_lds_max, e.grad_wide, e.grad_min_sources);
+    if (buf && cap > 0) { std::snprintf(buf, (size_t)cap, "%s", tmp); }
+    return n;
+}
+
 int nlos_sizeof_render_args(void) { return (int)sizeof(nlos_render_args); }
 
 int nlos_device_count(void) {
@@ -583,8 +596,8 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     c->path_retry_workgroups = 0;
 
     mark(c, 0, st);
-    static const int tile_threshold_b = [] { const char* e = std::getenv("NLOS_TILE_THRESHOLD"); return e ? std::atoi(e) : 6200; }();
-    static const bool lazy_enabled = [] { const char* e = std::getenv("NLOS_LAZY_TREE"); return !e || std::atoi(e) != 0; }();
+    const int tile_threshold_b = nlos::env_switches().tile_threshold;
+    const bool lazy_enabled = nlos::env_switches().lazy_tree;
     // the single-workgroup grid back-end reads the records and the root box only: build the tree when (if) it is needed
     const bool v1_point = a->v1_sampled_point && mode == NLOS_MODE_TRANSIENT && !a->sensor;      // BVH back-end only
     const bool lazy_build = lazy_enabled && nF <= tile_threshold_b && a->force_bvh != 1 && !v1_point;
@@ -634,7 +647,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     // Residual formed by pass 2 itself (round 4): vertex gradient of this call's own forward rows, confocal; k_residual's
     // other chores (clearing the gradient output, the pathlengths) then ride in the grid kernel's first workgroups, and the
     // step holds no residual launch.  Whether the launcher that runs carries them is known after the launch (note.prologue_done).
-    static const bool fuse_enabled = [] { const char* e = std::getenv("NLOS_FUSE_RESIDUAL"); return !e || std::atoi(e) != 0; }();
+    const bool fuse_enabled = nlos::env_switches().fuse_residual;
     const bool fuse_candidate = fuse_enabled && mode == NLOS_MODE_GRADIENT && !a->residual && !a->sensor && !a->reuse_visibility;
     fa.zero = nullptr; fa.zero_n = 0; fa.pathlengths = nullptr; fa.path_lb = lb; fa.path_res = res; fa.path_T = T;
     if (fuse_candidate) {
@@ -648,7 +661,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.retry = nullptr;
     fa.need_tree = c->tree_complete ? nullptr : c->lazy_flag.as<int>();
     fa.tiles_x = fa.tiles_y = fa.tile_cap = 0;
-    static const int tile_threshold = [] { const char* e = std::getenv("NLOS_TILE_THRESHOLD"); return e ? std::atoi(e) : 6200; }();
+    const int tile_threshold = nlos::env_switches().tile_threshold;
     int chunk_L = L > 0 ? L : 1;                       // sources per pass-1 launch
     if (nF <= tile_threshold && a->force_bvh != 1 && !v1_point) {
         rc = c->live.ensure(sizeof(uint16_t) * (size_t)(L > 0 ? L : 1) * nF + 16);
@@ -663,7 +676,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         // (front + back side, several depth layers) hold up to ~4.5x the mean, and the subset capacity is bounded by
         // the 14-bit entry index (overflowing tiles fall back to the BVH query by themselves);
         // scratch = 8 B per (source, tile, slot)
-        static const int tile_tris = [] { const char* e = std::getenv("NLOS_TILE_TRIS"); return e && std::atoi(e) > 0 ? std::atoi(e) : 3000; }();
+        const int tile_tris = nlos::env_switches().tile_tris;
         const int nt = (nF + tile_tris - 1) / tile_tris;
         int side = 1;
         while (side * side < nt) ++side;
@@ -674,11 +687,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         // the per-(source, tile) subsets are the largest scratch of the path (8 B per slot): bounded to 32 GB by
         // rendering the sources in chunks (NLOS_TILE_SCRATCH_MAX overrides the bound; nlos_ctx_last_path reports
         // the number of chunks)
-        static const unsigned long long scratch_max = [] {
-            const char* e = std::getenv("NLOS_TILE_SCRATCH_MAX");
-            const unsigned long long v = e ? std::strtoull(e, nullptr, 10) : 0ull;
-            return v > 0 ? v : (32ull << 30);
-        }();
+        const unsigned long long scratch_max = nlos::env_switches().tile_scratch_max;
         const unsigned long long per_source = (unsigned long long)tiles * (unsigned long long)tcap;
         unsigned long long max_l = scratch_max / (8ull * per_source);
         if (max_l < 1) max_l = 1;
@@ -733,7 +742,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         fa.vis = c->vis.as<uint32_t>();
         // item masks beside the words: the launcher that runs decides which of the two pass 1 records (the grid kernel
         // of confocal renders takes the masks; pairs, tiled grid and BVH back-end keep the per-face words)
-        static const bool items_enabled = [] { const char* e = std::getenv("NLOS_VIS_ITEMS"); return !e || std::atoi(e) != 0; }();
+        const bool items_enabled = nlos::env_switches().vis_items;
         if (items_enabled && !skip_pass1 && spt <= 32 && fa.live && !fa.tile_list) {
             const int stride = (int)(((size_t)nF * spt + 63) / 64) + 2;
             rc = c->vis_items.ensure(sizeof(unsigned long long) * (size_t)L * stride + 16);
@@ -741,7 +750,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
             fa.vis_items = c->vis_items.as<unsigned long long>();
             fa.items_stride = stride;
             // geometry cache for the pass 2 of THIS call (vertex-gradient modes, confocal): 24 B per ray of the live lists
-            static const bool geo_enabled = [] { const char* e = std::getenv("NLOS_GEO_CACHE"); return !e || std::atoi(e) != 0; }();
+            const bool geo_enabled = nlos::env_switches().geo_cache;
             // (spt <= 8 only: a 64-ray item writes spt segments of 64 / spt consecutive records; at spt = 19 -- the 1 055-face
             // mannequin -- those are 54-byte pieces, and the streaming stores of partial lines triple pass 1: 1.09 -> 2.80 ms,
             // profiles/r04_side_bench.log; such renders keep the recomputing pass 2)
@@ -750,7 +759,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
                 // the device has free, whichever is less -- and skipped when the allocation does not succeed (pass 2 then
                 // regenerates its samples).  DevBuf::try_ensure: exact size, the old buffer survives a failed growth, the
                 // last-error string stays clean.
-                static const double geo_env_gb = [] { const char* e = std::getenv("NLOS_GEO_CACHE_MAX_GB"); return e ? std::atof(e) : -1.0; }();
+                const double geo_env_gb = nlos::env_switches().geo_cache_max_gb;
                 const size_t geo_bytes = sizeof(float) * 6 * (size_t)L * (size_t)nF * (size_t)spt + 16;
                 size_t geo_max = (size_t)32 << 30;
                 if (geo_env_gb >= 0.0) {
@@ -1066,7 +1075,7 @@ static int render_product(nlos_ctx* c, const nlos_render_args* a, void* stream) 
     const int spt = 1 + ((a->num_samples - 1) / nF);
     const bool grad = a->mode == NLOS_MODE_GRADIENT;
     const int fwd_refine = grad ? (a->sigma_bin < 5 ? 1 : a->refine_scale) : a->refine_scale;
-    static const int tile_threshold = [] { const char* e = std::getenv("NLOS_TILE_THRESHOLD"); return e ? std::atoi(e) : 6200; }();
+    const int tile_threshold = nlos::env_switches().tile_threshold;
     const int Ltot = (a->total_sources > 0 ? a->total_sources : La) * Sb;      // measurements the gradient is averaged over
     const bool fast = !a->product_pairs && !a->vertex_normal && !a->albedo && !a->use_ggx && a->force_bvh == 0 && nF >= 64 &&
                       nF <= tile_threshold && spt <= 32 && fwd_refine == 1 && (size_t)T * sizeof(double) <= 48 * 1024 && La > 0 &&
@@ -1099,7 +1108,7 @@ static int render_product(nlos_ctx* c, const nlos_render_args* a, void* stream) 
     c->path_items_sources = 0;
     c->path_retry_workgroups = 0;
     mark(c, 0, st);
-    static const bool lazy_enabled = [] { const char* e = std::getenv("NLOS_LAZY_TREE"); return !e || std::atoi(e) != 0; }();
+    const bool lazy_enabled = nlos::env_switches().lazy_tree;
     rc = ensure_bvh(c, a->vertices, nV, a->faces, nF, a->reuse_bvh != 0, a->mesh_generation, st, lazy_enabled);
     if (rc) return rc;
     if (!c->tree_complete) note.lazy_build = &c->lazy_args;
@@ -1278,20 +1287,30 @@ int64_t nlos_ctx_debug_read(nlos_ctx* c, int what, void* host_out, int64_t max_b
     DeviceGuard guard(c->device);
     // what = 2: per-workgroup path codes of the last single-workgroup grid launch (0 normal, 1 redone with the
     // whole CU's LDS, 0x100 + R: redone on a grid coarsened to R x R)
-    const DevBuf* b = what == 0 ? &c->vis : (what == 1 ? &c->face_id : (what == 2 ? &c->tile_count : nullptr));
+    // what = 3: a 16-byte digest of the accepted-sample words (what = 0's array), computed on the device
+    const DevBuf* b = (what == 0 || what == 3) ? &c->vis : (what == 1 ? &c->face_id : (what == 2 ? &c->tile_count : nullptr));
     if (!b || !b->p) return -(int64_t)fail(NLOS_ERR_ARG, "nlos_ctx_debug_read: nothing to read");
     size_t n = 0;
-    if (what == 0) n = sizeof(uint32_t) * (size_t)c->vis_key.L * (size_t)((c->vis_key.spt + 31) / 32) * (size_t)c->vis_key.F;
+    if (what == 0 || what == 3) n = sizeof(uint32_t) * (size_t)c->vis_key.L * (size_t)((c->vis_key.spt + 31) / 32) * (size_t)c->vis_key.F;
     else if (what == 1) n = sizeof(int) * (size_t)c->built_F;
     else n = (size_t)max_bytes;
-    if (n > (size_t)max_bytes) n = (size_t)max_bytes;
+    if (what != 3 && n > (size_t)max_bytes) n = (size_t)max_bytes;
     if (n > b->cap) n = b->cap;
     hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess && what == 0 && c->vis_is_items) {
+    if (e == hipSuccess && (what == 0 || what == 3) && c->vis_is_items) {
         // the cache is held as item masks: per-face words for the reader
         nlos::launch_items_to_words(c->vis_items.as<unsigned long long>(), c->vis_items_stride, c->live.as<uint16_t>(), c->vis_key.L,
                                     c->vis_key.F, c->vis_key.spt, c->vis.as<uint32_t>(), nullptr);
         e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess && what == 3) {
+        if (max_bytes < 16 || c->status.cap < 512) return -(int64_t)fail(NLOS_ERR_ARG, "nlos_ctx_debug_read(3): needs 16 bytes");
+        unsigned long long* dg = c->status.as<unsigned long long>() + 56;      // scratch words behind the status / counters
+        nlos::launch_digest_u32(c->vis.as<uint32_t>(), n / sizeof(uint32_t), dg, nullptr);
+        e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(host_out, dg, 16, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return -(int64_t)fail(NLOS_ERR_HIP, std::string("nlos_ctx_debug_read: ") + hipGetErrorString(e));
+        return 16;
     }
     if (e == hipSuccess) e = hipMemcpy(host_out, b->p, n, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return -(int64_t)fail(NLOS_ERR_HIP, std::string("nlos_ctx_debug_read: ") + hipGetErrorString(e));

@@ -21,6 +21,24 @@ struct LaunchNote {
     const char* err_what = nullptr;
 };
 extern thread_local LaunchNote* tl_note;
+
+// Every behaviour-changing environment switch of the library, read ONCE per process by one accessor (round 6: the launchers
+// and nlos_render used to read them through separate function-local statics); nlos_env_report() lists them with their values.
+struct EnvSwitches {
+    int tile_threshold;                  // NLOS_TILE_THRESHOLD   faces above which pass 1 uses the tiled grid            (6200)
+    bool lazy_tree;                      // NLOS_LAZY_TREE        build the BVH only if a back-end asks for it            (1)
+    bool fuse_residual;                  // NLOS_FUSE_RESIDUAL    pass 2 forms the residual itself                        (1)
+    int tile_tris;                       // NLOS_TILE_TRIS        triangles per slope-space tile                          (3000)
+    unsigned long long tile_scratch_max; // NLOS_TILE_SCRATCH_MAX bytes of tile-subset scratch before sources are chunked (32 GiB)
+    bool vis_items;                      // NLOS_VIS_ITEMS        visibility cache as item masks                          (1)
+    bool geo_cache;                      // NLOS_GEO_CACHE        pass 1 -> pass 2 geometry cache                         (1)
+    double geo_cache_max_gb;             // NLOS_GEO_CACHE_MAX_GB bound of that cache (< 0: min(32 GB, half of free))     (-1)
+    size_t row_lds_max;                  // NLOS_ROW_LDS_MAX      bytes of histogram row kept in LDS                      (10240)
+    int grad_wide;                       // NLOS_GRAD_WIDE        pass 2 may use its wide instance                        (1)
+    int grad_min_sources;                // NLOS_GRAD_MIN_SOURCES sources per pass-2 workgroup at least (small L)         (1)
+};
+const EnvSwitches& env_switches();
+void launch_digest_u32(const uint32_t* w, size_t n, unsigned long long* out, hipStream_t stream);
 inline void note_hip(hipError_t e, const char* what) {
     if (e != hipSuccess && tl_note && tl_note->err == hipSuccess) { tl_note->err = e; tl_note->err_what = what; }
 }

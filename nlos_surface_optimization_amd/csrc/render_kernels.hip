@@ -201,13 +201,63 @@ __global__ __launch_bounds__(256) void k_zero_f64(double* p, size_t n) {
 
 thread_local LaunchNote* tl_note = nullptr;
 
+// Diagnostics (nlos_ctx_debug_read what = 3, tools/soak.py): a position-dependent 2 x 64-bit digest of `n` 32-bit words --
+// of the accepted-sample words per (source, face), which do not depend on the order in which workgroups, waves and atomics
+// happened to run: two renders of the same inputs must give the same digest.
+__global__ __launch_bounds__(256) void k_digest_u32(const uint32_t* __restrict__ w, size_t n, unsigned long long* __restrict__ out) {
+    unsigned long long a = 0ull, b = 0ull;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long z = ((unsigned long long)w[i] + 0x9E3779B97F4A7C15ull) * (2ull * i + 1ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        a += z ^ (z >> 31);
+        b ^= z * (i + 0x632BE59BD9B4E019ull);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off);
+        b ^= __shfl_xor(b, off);
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], a); atomicXor(&out[1], b); }
+}
+void launch_digest_u32(const uint32_t* w, size_t n, unsigned long long* out, hipStream_t stream) {
+    note_hip(hipMemsetAsync(out, 0, 16, stream), "hipMemsetAsync(digest)");
+    hipLaunchKernelGGL(k_digest_u32, dim3(1024), dim3(256), 0, stream, w, n, out);
+}
+
+const EnvSwitches& env_switches() {
+    static const EnvSwitches e = [] {
+        auto geti = [](const char* n, long long d) { const char* v = std::getenv(n); return v ? std::atoll(v) : d; };
+        EnvSwitches s;
+        s.tile_threshold = (int)geti("NLOS_TILE_THRESHOLD", 6200);
+        s.lazy_tree = geti("NLOS_LAZY_TREE", 1) != 0;
+        s.fuse_residual = geti("NLOS_FUSE_RESIDUAL", 1) != 0;
+        const long long tt = geti("NLOS_TILE_TRIS", 3000);
+        s.tile_tris = tt > 0 ? (int)tt : 3000;
+        const char* sm = std::getenv("NLOS_TILE_SCRATCH_MAX");
+        const unsigned long long smv = sm ? std::strtoull(sm, nullptr, 10) : 0ull;
+        s.tile_scratch_max = smv > 0 ? smv : (32ull << 30);
+        s.vis_items = geti("NLOS_VIS_ITEMS", 1) != 0;
+        s.geo_cache = geti("NLOS_GEO_CACHE", 1) != 0;
+        const char* gm = std::getenv("NLOS_GEO_CACHE_MAX_GB");
+        s.geo_cache_max_gb = gm ? std::atof(gm) : -1.0;
+        s.row_lds_max = (size_t)geti("NLOS_ROW_LDS_MAX", 10 * 1024);
+        s.grad_wide = (int)geti("NLOS_GRAD_WIDE", 1);
+        s.grad_min_sources = (int)geti("NLOS_GRAD_MIN_SOURCES", 1);
+        return s;
+    }();
+    return e;
+}
+
 void launch_forward(const ForwardArgs& a, hipStream_t stream) {
     if (a.src.L <= 0) return;
     const size_t row_bytes = (size_t)a.sp.nbins * sizeof(double);
-    // the histogram row of a source lives in LDS while it leaves room for the grid (<= 9 KB: 1152 bins);
-    // longer rows are accumulated with global atomics -- only ~12 k accepted samples per source land in them,
-    // which costs 4 % (measured: 2048 bins 5.4 ms with the row in LDS and the grid squeezed, 2.6 ms this way)
-    static const size_t row_lds_max = [] { const char* e = std::getenv("NLOS_ROW_LDS_MAX"); return e ? (size_t)std::atol(e) : (size_t)9 * 1024; }();
+    // the histogram row of a source lives in LDS while it leaves room for the grid (<= 10 KB: 1280 bins);
+    // longer rows are accumulated with global atomics -- only ~12 k accepted samples per source land in them
+    // (measured: 2048 bins 5.4 ms with the row in LDS and the grid squeezed, 2.6 ms this way).  Round 6: the bound went from
+    // 9 KB to 10 KB to cover the 1 200 bins every experiment script of the reference uses (exp_bunny/test.py:33-34): bunny_5k
+    // 64x64x1200 forward 1.582 -> 1.391 ms with the row in LDS (64 of 4 096 sources coarsen their grid for the 400 bytes);
+    // at 1 536 bins the row in LDS loses (1.532 -> 1.634 ms, 2 027 sources coarsen): profiles/r06_row_lds_max.log
+    const size_t row_lds_max = env_switches().row_lds_max;
     const int rows_in_lds = (!a.mode_intensity && row_bytes <= row_lds_max) ? 1 : 0;
     if (!rows_in_lds && !a.mode_intensity) launch_zero_f64(a.rows, (size_t)a.src.L * a.sp.nbins, stream);
     if (tl_note) tl_note->rows_in_lds = rows_in_lds;

@@ -319,6 +319,16 @@ class TransientRenderer:
                 raise _lib.NlosError("nlos_ctx_debug_read(%d) returned %d, expected %d" % (what, n, arr.nbytes))
         return vis, fid
 
+    def debug_visibility_digest(self):
+        """Diagnostics: 2 x 64-bit digest of the accepted-sample words of the last render that kept them, computed on the
+        device (tools/soak.py: equal inputs must give equal digests, whatever order the workgroups ran in)."""
+        import numpy as np
+        dg = np.zeros(2, np.uint64)
+        n = self._lib.nlos_ctx_debug_read(self._h, 3, dg.ctypes.data_as(ctypes.c_void_p), dg.nbytes)
+        if n != 16:
+            raise _lib.NlosError("nlos_ctx_debug_read(3) returned %d" % n)
+        return int(dg[0]), int(dg[1])
+
     def debug_grid_paths(self, L):
         """Diagnostics: int32 [L] path code per source of the last single-workgroup grid launch (0 normal,
         0x100 + R coarsened to R x R after a cell-list overflow, 1 redone with the whole CU's LDS)."""
