@@ -1095,12 +1095,32 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                     float hu, hv;
                     ok = tri_test<LEAN>(tr, o, dir, t_self, hu, hv);
                     if (ok) {
-                        const V3 q = bary(1.0f - hu - hv, f.p0, hu, f.p1, hv, f.p2);
+                        const float hw = 1.0f - hu - hv;
+                        const V3 q = bary(hw, f.p0, hu, f.p1, hv, f.p2);
                         const V3 e = q - o;
                         const float dist = LEAN ? sqrt_cr(dot(e, e)) : sqrtf(dot(e, e));
-                        val = emax0(form_factor<LEAN>(-dot(f.fn, dir) * dot(on, dir), dist));
+                        // normal and albedo at THIS leg's hit (sample_geo_nc()'s expressions: they are the pair's when this
+                        // wall point is its laser)
+                        V3 nn = f.fn;
+                        if (FEAT & FEAT_VN)
+                            nn = bary(hw, ld3(a.sc.vertex_normal + 3 * (size_t)f.i0), hu, ld3(a.sc.vertex_normal + 3 * (size_t)f.i1), hv,
+                                      ld3(a.sc.vertex_normal + 3 * (size_t)f.i2));
+                        val = emax0(form_factor<LEAN>(-dot(nn, dir) * dot(on, dir), dist));
                         bin = __float_as_int(dist);
-                        ok = val > 0.0f;
+                        if (FEAT & (FEAT_VN | FEAT_ALB)) {
+                            // extended record: written HERE (normal and albedo are dead after this block; an occluded ray's record
+                            // is invalidated by rec_d staying 0); the sensor role needs the leg even where this form factor is 0
+                            const size_t at = (size_t)l * ((size_t)F * (size_t)spt) + (size_t)jg * (size_t)spt + (size_t)s;
+                            float* ex = a.rec_ext + at;
+                            const size_t es = a.rec_ext_stride;
+                            ex[0] = dir.x; ex[es] = dir.y; ex[2 * es] = dir.z;
+                            ex[3 * es] = nn.x; ex[4 * es] = nn.y; ex[5 * es] = nn.z;
+                            float al = 1.0f;
+                            if (FEAT & FEAT_ALB) al = hw * a.sc.albedo[f.i0] + hu * a.sc.albedo[f.i1] + hv * a.sc.albedo[f.i2];
+                            ex[6 * es] = al;
+                        } else {
+                            ok = val > 0.0f;
+                        }
                     }
                 }
             } else if (NCM == 1) {
@@ -1614,8 +1634,20 @@ bool grid_dispatch(const ForwardArgs& a, int rows_in_lds, hipStream_t stream) {
 // record pass of the product: one launch of the single-workgroup grid per set of wall points (face normals, Lambertian);
 // false: this scene is outside that kernel's range (the caller then renders the enumerated pairs)
 bool launch_forward_record(const ForwardArgs& a, hipStream_t stream) {
-    if (!a.rec_d || !a.rec_ff || a.src.sensor || a.tile_list || feat_of(a.sc, a.sp) != 0) return false;
-    return forward_grid_launch<0, 3>(a, 0, stream);
+    if (!a.rec_d || !a.rec_ff || a.src.sensor || a.tile_list) return false;
+    const int feat = feat_of(a.sc, a.sp);
+    if (feat != 0 && !a.rec_ext) return false;
+#ifdef NLOS_ONLY_FEAT0
+    return feat == 0 && forward_grid_launch<0, 3>(a, 0, stream);
+#else
+    switch (feat) {
+        case 0: return forward_grid_launch<0, 3>(a, 0, stream);
+        case FEAT_VN: return forward_grid_launch<FEAT_VN, 3>(a, 0, stream);
+        case FEAT_ALB: return forward_grid_launch<FEAT_ALB, 3>(a, 0, stream);
+        case FEAT_VN | FEAT_ALB: return forward_grid_launch<FEAT_VN | FEAT_ALB, 3>(a, 0, stream);
+        default: return false;          // GGX: the pair path
+    }
+#endif
 }
 
 // true: launched (single-workgroup grid, tiled grid or the two passes of non-confocal pairs);

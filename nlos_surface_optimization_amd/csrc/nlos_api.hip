@@ -1042,10 +1042,12 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
 }
 
 // Row N as the product of a laser set and a sensor set (include/nlos_hip.h, nlos_render_args.n_sensors).
-//   fast path  (face normals, no albedo, Lambertian, single-workgroup grid, spt <= 32, unrefined rows that fit LDS):
-//              one record pass per wall point (k_forward_grid<0, 3>: leg length + form factor of every sample the point
-//              sees), one combine kernel over the pairs (rows + accepted-sample words), then residual and the pair
-//              gradient kernel over the L x S measurements -- O(L + S) grid passes instead of 2 L S;
+//   fast path  (Lambertian, single-workgroup grid, spt <= 32, unrefined rows that fit LDS; face normals, or -- round 6 --
+//              vertex normals / albedo with the extended records):
+//              one record pass per wall point (k_forward_grid<FEAT, 3>: leg length + form factor of every sample the point
+//              sees; extended: + the leg's direction and the normal / albedo at its hit), one combine kernel over the pairs
+//              (rows + accepted-sample words), then residual and the pair gradient kernel over the L x S measurements --
+//              O(L + S) grid passes instead of 2 L S;
 //   otherwise  the pairs are enumerated into scratch arrays and rendered by the pair path on shared samples.
 // Both are the same function of the inputs (the product is defined as its pairs).
 static int render_product(nlos_ctx* c, const nlos_render_args* a, void* stream) {
@@ -1077,7 +1079,8 @@ static int render_product(nlos_ctx* c, const nlos_render_args* a, void* stream) 
     const int fwd_refine = grad ? (a->sigma_bin < 5 ? 1 : a->refine_scale) : a->refine_scale;
     const int tile_threshold = nlos::env_switches().tile_threshold;
     const int Ltot = (a->total_sources > 0 ? a->total_sources : La) * Sb;      // measurements the gradient is averaged over
-    const bool fast = !a->product_pairs && !a->vertex_normal && !a->albedo && !a->use_ggx && a->force_bvh == 0 && nF >= 64 &&
+    const bool ext = a->vertex_normal || a->albedo;      // extended records (round 6): normal + albedo of the laser leg, direction of the sensor leg
+    const bool fast = !a->product_pairs && !a->use_ggx && a->force_bvh == 0 && nF >= 64 &&
                       nF <= tile_threshold && spt <= 32 && fwd_refine == 1 && (size_t)T * sizeof(double) <= 48 * 1024 && La > 0 &&
                       a->source_stride <= 1;
     // ---- the enumerated pairs, on shared samples (what the product is defined as)
@@ -1113,14 +1116,14 @@ static int render_product(nlos_ctx* c, const nlos_render_args* a, void* stream) 
     if (rc) return rc;
     if (!c->tree_complete) note.lazy_build = &c->lazy_args;
     mark(c, 1, st);
-    nlos::SceneView sc = scene_view(c, nF, nV, nullptr, nullptr);
+    nlos::SceneView sc = scene_view(c, nF, nV, a->vertex_normal, a->albedo);
 
     // ---- record pass: lasers, then sensors (the same records serve both roles when the two sets are one array)
     const bool same_set = a->sensor == a->origin && a->sensor_normal == a->normal && Sb == La;
     const int W = same_set ? La : La + Sb;
     const size_t R = (size_t)nF * (size_t)spt;
     const int Wmax = La > Sb ? La : Sb;
-    rc = c->prod_rec.ensure(sizeof(float) * 2 * (size_t)W * R + 64);
+    rc = c->prod_rec.ensure(sizeof(float) * (ext ? 9 : 2) * (size_t)W * R + 64);
     if (!rc) rc = c->live.ensure(sizeof(uint16_t) * (size_t)Wmax * nF + 16);
     if (!rc) rc = c->cov.ensure(sizeof(uint16_t) * (size_t)Wmax * nF + 16);
     if (!rc) rc = c->tile_count.ensure(sizeof(int) * (size_t)Wmax + 16);
@@ -1128,6 +1131,8 @@ static int render_product(nlos_ctx* c, const nlos_render_args* a, void* stream) 
     float* rec_d = c->prod_rec.as<float>();
     float* rec_ff = rec_d + (size_t)W * R;
     HIP_TRY(hipMemsetAsync(rec_ff, 0, sizeof(float) * (size_t)W * R, st));      // ff = 0: not seen (d is read only where ff > 0)
+    float* rec_ext = ext ? rec_ff + (size_t)W * R : nullptr;                     // 7 arrays of W x R floats (ForwardArgs::rec_ext)
+    if (ext) HIP_TRY(hipMemsetAsync(rec_d, 0, sizeof(float) * (size_t)W * R, st));   // extended records: d = 0 means "not seen"
     nlos::ForwardArgs fa;
     std::memset(&fa, 0, sizeof(fa));
     fa.sc = sc;
@@ -1143,6 +1148,8 @@ static int render_product(nlos_ctx* c, const nlos_render_args* a, void* stream) 
         fa.src.L = side ? Sb : La;
         fa.rec_d = rec_d + (side ? (size_t)La * R : 0);
         fa.rec_ff = rec_ff + (side ? (size_t)La * R : 0);
+        fa.rec_ext = ext ? rec_ext + (side ? (size_t)La * R : 0) : nullptr;
+        fa.rec_ext_stride = (size_t)W * R;
         fa.need_tree = c->tree_complete || note.tree_built ? nullptr : c->lazy_flag.as<int>();
         ok_launch = nlos::launch_forward_record(fa, st);
         if (note.tree_built) c->tree_complete = true;
@@ -1161,6 +1168,10 @@ static int render_product(nlos_ctx* c, const nlos_render_args* a, void* stream) 
     pa.d_a = rec_d; pa.ff_a = rec_ff;
     pa.d_b = same_set ? rec_d : rec_d + (size_t)La * R;
     pa.ff_b = same_set ? rec_ff : rec_ff + (size_t)La * R;
+    pa.ext_a = ext ? rec_ext : nullptr;
+    pa.ext_b = ext ? (same_set ? rec_ext : rec_ext + (size_t)La * R) : nullptr;
+    pa.ext_stride = (size_t)W * R;
+    pa.sensor_normal = a->sensor_normal;
     pa.La = La; pa.Sb = Sb; pa.spt = spt; pa.nbins = T; pa.lb = lb; pa.ub = ub; pa.res = res;
     pa.rows = a->transient;
     pa.vis = nullptr;
@@ -1207,7 +1218,8 @@ static int render_product(nlos_ctx* c, const nlos_render_args* a, void* stream) 
         ga.tap_nb = 4 * a->sigma_bin + 1;
         ga.diff = c->diff.as<double>();
         ga.mode = 0;
-        ga.normal_term = a->normal_term < 0 ? 0 : (a->normal_term ? 1 : 0);      // (face normals: the reference rule gives 0)
+        // (nlos_render's rule: smoothed_transient/...GradientRenderer.cpp's normal term only with vertex normals and testing_flag 0)
+        ga.normal_term = a->normal_term < 0 ? ((a->testing_flag == 0 && a->vertex_normal != nullptr) ? 1 : 0) : (a->normal_term ? 1 : 0);
         ga.out = a->gradient;
         ga.lds_grad = 1;
         nlos::launch_gradient(ga, st);

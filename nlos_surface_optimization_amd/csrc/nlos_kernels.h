@@ -170,6 +170,13 @@ struct ForwardArgs {
     // length of the leg and its clamped form factor, 0 where the sample is not seen from that wall point
     float* rec_d;            // [L, F * spt] or null
     float* rec_ff;           // [L, F * spt]
+    // scenes with vertex normals / albedo (round 6): a pair's normal and albedo are interpolated at the LASER leg's hit, so the
+    // sensor leg's form factor depends on the laser; what makes the legs separable again -- this leg's unit direction (the
+    // sensor role: the combine kernel forms its cosine with the laser's normal), and the normal + albedo interpolated at this
+    // leg's own hit (the laser role).  rec_ext: 7 arrays of [L, F * spt] floats: dir.x, dir.y, dir.z, n.x, n.y, n.z, albedo;
+    // rec_d > 0 then means "seen from this wall point" (rec_ff may be 0 there: it is the laser role's form factor).
+    float* rec_ext;          // or null (face normals, no albedo: rec_d / rec_ff alone)
+    size_t rec_ext_stride;   // floats between two of the seven arrays
     int* need_tree;          // lazy scene build: raised by first-launch workgroups that need the BVH query (they then leave it to
                              // the second launch, in front of which the tree is completed); null = the tree exists
 };
@@ -182,6 +189,9 @@ struct ProductArgs {
     SceneView sc;
     const float* d_a; const float* ff_a;   // laser records [La, F * spt]
     const float* d_b; const float* ff_b;   // sensor records [Sb, F * spt]
+    const float* ext_a; const float* ext_b;   // extended records (ForwardArgs::rec_ext) of the laser / sensor set, or null
+    size_t ext_stride;
+    const float* sensor_normal;            // [Sb, 3] (extended records: the sensor's wall cosine is formed in the combine)
     int La, Sb, spt, nbins;
     float lb, ub, res;
     double* rows;

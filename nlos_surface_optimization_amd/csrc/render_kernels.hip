@@ -139,6 +139,11 @@ __global__ __launch_bounds__(256) void k_bary_to_world(const float* V, const int
 // both legs did and d1 + d2 lies in the window -- the expressions of the pair kernels (k_forward_grid<FEAT, 2>,
 // sample_geo_nc) term for term: val = (area ffa) ffb, bin = floor(((d1 + d2) - lb) / res), (double)val / spt.
 // One lane per face, its spt strata in turn; the accepted-sample word of (pair, face) is what pass 2 reads.
+// EXT (round 6): scenes with vertex normals / albedo.  The pair's normal and albedo are the laser leg's (interpolated at ITS hit,
+// sample_geo_nc()), so the laser record carries them and its own clamped form factor, the sensor record the leg's unit
+// direction and length; the sensor's form factor is formed here, with sample_geo_nc()'s / k_forward_grid<FEAT, 2>'s expressions
+// term for term: numb = -dot(n, dirB) * dot(onb, dirB), ffb = max(0, numb / d2 / d2), val = ((area * alb) * ffa) * ffb.
+template <bool EXT>
 __global__ __launch_bounds__(256) void k_product_combine(ProductArgs a) {
     extern __shared__ double s_prow[];
     const int pair = blockIdx.x;
@@ -152,6 +157,10 @@ __global__ __launch_bounds__(256) void k_product_combine(ProductArgs a) {
     const float* __restrict__ dB = a.d_b + (size_t)j * R;
     const float* __restrict__ fB = a.ff_b + (size_t)j * R;
     const double inv_spt = 1.0 / (double)spt;
+    const float* __restrict__ xA = EXT ? a.ext_a + (size_t)i * R : nullptr;
+    const float* __restrict__ xB = EXT ? a.ext_b + (size_t)j * R : nullptr;
+    const size_t es = a.ext_stride;
+    const V3 onb = EXT ? ld3(a.sensor_normal + 3 * (size_t)j) : mk(0.0f, 0.0f, 1.0f);
     for (int jf = threadIdx.x; jf < F; jf += blockDim.x) {
         uint32_t word = 0u;
         const size_t r0 = (size_t)jf * (size_t)spt;
@@ -159,16 +168,28 @@ __global__ __launch_bounds__(256) void k_product_combine(ProductArgs a) {
         for (int s = 0; s < spt; ++s) {
             const float ffa = fA[r0 + s];
             if (!(ffa > 0.0f)) continue;
-            const float ffb = fB[r0 + s];
+            float ffb, alb = 1.0f;
+            const float d2 = dB[r0 + s];
+            if (EXT) {
+                if (!(d2 > 0.0f)) continue;                                  // not seen from the sensor
+                const size_t at = r0 + s;
+                const V3 n = mk(xA[3 * es + at], xA[4 * es + at], xA[5 * es + at]);
+                const V3 dirB = mk(xB[at], xB[es + at], xB[2 * es + at]);
+                const float numb = -dot(n, dirB) * dot(onb, dirB);
+                ffb = emax0(form_factor<false>(numb, d2));
+                alb = xA[6 * es + at];
+            } else {
+                ffb = fB[r0 + s];
+            }
             if (!(ffb > 0.0f)) continue;
-            const float d1 = dA[r0 + s], d2 = dB[r0 + s];
+            const float d1 = dA[r0 + s];
             const float tot = d1 + d2;
             if (!((tot <= a.ub) && (tot >= a.lb))) continue;
             word |= 1u << s;
             if (area == 0.0f) area = a.sc.tris[kTriStride * jf + 3].z;
             const int bin = (int)floorf((tot - a.lb) / a.res);
             if (bin < 0 || bin >= nbins) continue;
-            const float val = area * ffa * ffb;
+            const float val = EXT ? area * alb * ffa * ffb : area * ffa * ffb;
             lds_add_f64(&s_prow[bin], (double)val * inv_spt);
         }
         if (a.vis) a.vis[(size_t)pair * F + jf] = word;
@@ -296,9 +317,15 @@ void launch_residual(const ResidualArgs& a, hipStream_t stream) {
 void launch_product_combine(const ProductArgs& a, hipStream_t stream) {
     if (a.La <= 0 || a.Sb <= 0) return;
     const size_t lds = (size_t)a.nbins * sizeof(double);
-    note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_product_combine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+    if (a.ext_a && a.ext_b) {
+        note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_product_combine<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                 "hipFuncSetAttribute(k_product_combine)");
+        hipLaunchKernelGGL(k_product_combine<true>, dim3((unsigned)((size_t)a.La * a.Sb)), dim3(256), lds, stream, a);
+        return;
+    }
+    note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_product_combine<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
              "hipFuncSetAttribute(k_product_combine)");
-    hipLaunchKernelGGL(k_product_combine, dim3((unsigned)((size_t)a.La * a.Sb)), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(k_product_combine<false>, dim3((unsigned)((size_t)a.La * a.Sb)), dim3(256), lds, stream, a);
 }
 
 void launch_expand_pairs(const float* laser, const float* lnormal, const float* sensor, const float* snormal, int La, int Sb,

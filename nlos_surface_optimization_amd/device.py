@@ -225,17 +225,20 @@ class TransientRenderer:
     def render_product(self, laser, laser_normal, sensor, sensor_normal, vertices, faces, num_sample, lower_bound,
                        upper_bound, resolution, data=None, weight=None, refine_scale=None, sigma_bin=1, testing_flag=1,
                        loss_flag=0, gradient=None, zero_gradient=False, pairs=False, seed=None, total_lasers=0,
-                       out=None):
+                       out=None, vertex_normal=None, albedo=None):
         """Row N as a product (include/nlos_hip.h, nlos_render_args.n_sensors): every (laser[i], sensor[j]) combination on
         sample points shared by all wall points.  Returns (transient [L, S, T] f64, gradient [V, 3] f64 or None,
         pathlengths); with `data` ([L, S, T]; `weight` likewise, default 1) the vertex gradient of
         sum w (data - T)^2 / (L S) is computed (accumulated into `gradient` if given).  pairs=True renders the enumerated
-        pairs instead of the record + combine kernels (the definition; same results)."""
+        pairs instead of the record + combine kernels (the definition; same results).  vertex_normal / albedo: shading
+        normals and per-vertex albedo, interpolated at the LASER leg's hit as in the pair renderer (record + combine kernels
+        with extended records since round 6)."""
         grad = data is not None
         if refine_scale is None:
             refine_scale = 10 if grad else 1
         a = self._args(_lib.MODE_GRADIENT if grad else _lib.MODE_TRANSIENT, laser, laser_normal, vertices, faces, num_sample,
-                       lower_bound, upper_bound, resolution, refine_scale, sigma_bin, seed=seed, total_sources=total_lasers)
+                       lower_bound, upper_bound, resolution, refine_scale, sigma_bin, vertex_normal=vertex_normal, albedo=albedo,
+                       seed=seed, total_sources=total_lasers)
         _want(sensor, torch.float32, "sensor", 2); _want(sensor_normal, torch.float32, "sensor_normal", 2)
         assert sensor.shape[1] == 3 and sensor_normal.shape == sensor.shape and sensor.shape[0] > 0, "sensor/sensor_normal need to be Sx3"
         L, S, T = laser.shape[0], sensor.shape[0], self.num_bins(lower_bound, upper_bound, resolution)
@@ -259,7 +262,7 @@ class TransientRenderer:
             a.zero_gradient = 1 if zero_gradient else 0
             a.data, a.weight, a.gradient = _dptr(data), _dptr(weight), _dptr(gradient)
             a.testing_flag, a.loss_test = int(testing_flag), int(loss_flag)
-        self._run(a, (laser, laser_normal, sensor, sensor_normal, vertices, faces, data, weight))
+        self._run(a, (laser, laser_normal, sensor, sensor_normal, vertices, faces, data, weight, vertex_normal, albedo))
         return transient, (gradient if grad else None), path
 
     def render_gradient_scalar(self, origin, normal, vertices, faces, num_sample, lower_bound, upper_bound,

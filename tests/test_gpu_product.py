@@ -199,3 +199,50 @@ def test_product_gradient_rejects_what_nlos_render_rejects(bunny, renderer, bad)
     # the context is still usable, and the same arguments without the defect render
     t, _, _ = renderer.render_product(tl, tln, ts, tsn, tv, tf, 3 * f.shape[0], LB, UB, RES)
     assert float(t.sum()) > 0
+
+
+@pytest.mark.parametrize("case", ["vertex_normals", "albedo", "both", "both_testing_flag_0"])
+def test_shading_normals_and_albedo_through_the_extended_records(orc, bunny, renderer, case):
+    """Round 6: the pair's normal and albedo are interpolated at the LASER leg's hit, so the sensor's form factor depends on
+    the laser; the records now carry what makes the legs separable again (laser: normal + albedo + its own form factor,
+    sensor: unit direction + length) and such scenes stay on the record + combine kernels -- same rows as the enumerated
+    pairs (the definition) and as the pair oracle, gradient to the pair kernels' tolerance."""
+    from conftest import vertex_normals
+    v, f = bunny
+    la, lan = _wall([[0.1, 0.0, 0], [-0.2, 0.1, 0], [0.05, -0.25, 0], [0.3, 0.0, 0.45]])
+    sb, sbn = _wall([[0.1, 0.0, 0], [0.2, 0.2, 0], [-0.15, -0.05, 0]])
+    ns = 3 * f.shape[0]
+    rs = np.random.RandomState(8)
+    vn = vertex_normals(v, f) if case != "albedo" else None
+    if vn is not None:       # shading normals that differ from the geometric ones
+        vn = vn + 0.15 * rs.standard_normal(vn.shape).astype(np.float32)
+        vn = np.ascontiguousarray(vn / np.linalg.norm(vn, axis=1, keepdims=True), np.float32)
+    alb = np.ascontiguousarray(0.3 + 0.7 * rs.random_sample(v.shape[0]), np.float32) if case != "vertex_normals" else None
+    tf_flag = 0 if case == "both_testing_flag_0" else 1
+    okw = dict(vnormal=vn, albedo=alb)
+    t_ref, _, _ = orc.render_product(la, lan, sb, sbn, v, f, ns, LB, UB, RES, accel=1, seed=11, **okw)
+    t_plain, _, _ = orc.render_product(la, lan, sb, sbn, v, f, ns, LB, UB, RES, accel=1, seed=11)
+    assert t_ref.sum() > 0 and rel_l2(t_ref, t_plain) > 1e-3          # the features do change the rows
+    tl, tln, ts, tsn, tv, tf, tvn, talb = _dev(la, lan, sb, sbn, v, f, vn, alb)
+    gkw = dict(vertex_normal=tvn, albedo=talb)
+    t, _, _ = renderer.render_product(tl, tln, ts, tsn, tv, tf, ns, LB, UB, RES, **gkw)
+    p = renderer.last_path()
+    assert p["backend"] == "grid"
+    assert rel_l2(t.cpu().numpy(), t_ref) < 1e-12
+    t2, _, _ = renderer.render_product(tl, tln, ts, tsn, tv, tf, ns, LB, UB, RES, pairs=True, **gkw)
+    assert rel_l2(t2.cpu().numpy(), t_ref) < 1e-12
+    data = t_ref * (1 + 0.3 * rs.standard_normal(t_ref.shape))
+    w = 0.5 + rs.random_sample(t_ref.shape)
+    _, g_ref, _ = orc.render_product(la, lan, sb, sbn, v, f, ns, LB, UB, RES, data=data, weight=w, accel=1, seed=11, sigma_bin=1,
+                                     testing_flag=tf_flag, **okw)
+    td, tw = _dev(data, w)
+    t3, g3, _ = renderer.render_product(tl, tln, ts, tsn, tv, tf, ns, LB, UB, RES, data=td, weight=tw, testing_flag=tf_flag, **gkw)
+    assert rel_l2(t3.cpu().numpy(), t_ref) < 1e-12 and rel_l2(g3.cpu().numpy(), g_ref) < 1e-4
+    _, g4, _ = renderer.render_product(tl, tln, ts, tsn, tv, tf, ns, LB, UB, RES, data=td, weight=tw, testing_flag=tf_flag, pairs=True, **gkw)
+    assert rel_l2(g4.cpu().numpy(), g3.cpu().numpy()) < 1e-6
+    # one set in both roles: a single record pass serves lasers and sensors
+    ws, wsn = _wall([[0.1, 0.0, 0], [-0.2, 0.1, 0], [0.0, 0.2, 0]])
+    s_ref, _, _ = orc.render_product(ws, wsn, ws, wsn, v, f, ns, LB, UB, RES, accel=1, seed=11, **okw)
+    tws, twsn = _dev(ws, wsn)
+    s_gpu, _, _ = renderer.render_product(tws, twsn, tws, twsn, tv, tf, ns, LB, UB, RES, **gkw)
+    assert rel_l2(s_gpu.cpu().numpy(), s_ref) < 1e-12
