@@ -408,11 +408,14 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     // handed from workgroup to workgroup instead of one region per source was tried, to keep the scratch in cache:
     // the regions then migrate between the XCDs' L2s -- 1.75 GB of fabric traffic per launch instead of 0.49 GB and
     // 2.29 ms instead of 1.91 ms.)
-    uint16_t* g_live = a.live + (size_t)blockIdx.x * (TILED ? a.tile_cap : F);
-    uint16_t* g_cov = a.cov + (size_t)blockIdx.x * (TILED ? a.tile_cap : F);     // per-triangle cell coverage, count -> fill pass
-    uint32_t* tl = TILED ? a.tile_list + (size_t)blockIdx.x * a.tile_cap : nullptr;
+    // (one workgroup per source: the source this workgroup renders, in the launcher's order when it has one -- wgid replaces
+    // blockIdx.x everywhere below; the tiled grid keeps its (source, tile) numbering)
+    const unsigned wgid = (!TILED && a.perm) ? (unsigned)a.perm[blockIdx.x] : blockIdx.x;
+    uint16_t* g_live = a.live + (size_t)wgid * (TILED ? a.tile_cap : F);
+    uint16_t* g_cov = a.cov + (size_t)wgid * (TILED ? a.tile_cap : F);     // per-triangle cell coverage, count -> fill pass
+    uint32_t* tl = TILED ? a.tile_list + (size_t)wgid * a.tile_cap : nullptr;
 
-    const int l = TILED ? (int)(blockIdx.x / (unsigned)ntiles) : (int)blockIdx.x;
+    const int l = TILED ? (int)(wgid / (unsigned)ntiles) : (int)wgid;
     const int tid = threadIdx.x, NT = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = NT >> 6;
     const V3 o = ld3((NCM == 1 ? a.src.sensor : a.src.origin) + 3 * (size_t)l);
@@ -489,7 +492,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
         // lazy scene build: the tree does not exist yet.  This source (scene not strictly in front of its wall point)
         // needs the BVH query: flag it for the second launch, in front of which the tree is completed
         if (tid == 0) {
-            a.retry[blockIdx.x] = pass + 1;
+            a.retry[wgid] = pass + 1;
             __hip_atomic_store(a.need_tree, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return false;
@@ -511,7 +514,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             if (tile != 0) return false;               // tile 0 handles such a source alone (BVH queries)
         } else {
             // ---- tile subset, binned by k_tile_bin
-            const int nsel = a.tile_count[blockIdx.x];
+            const int nsel = a.tile_count[wgid];
 #ifdef NLOS_FWD_STAMPS
             if (tid == 0 && a.dbg) {
                 if (nsel > a.tile_cap) atomicAdd((unsigned long long*)&a.dbg[22], 1ull);
@@ -737,7 +740,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
         if (!COARSE && R > 8) return true;                     // cell lists overflow: once more, coarser, right here
         if (pass < last_pass && a.retry) {
             if (tid == 0) {
-                a.retry[blockIdx.x] = pass + 1;      // still too many entries: redo in the big-LDS launch
+                a.retry[wgid] = pass + 1;      // still too many entries: redo in the big-LDS launch
                 // (which may have to fall back to the BVH query: a lazily built scene gets its tree now)
                 if (a.need_tree) __hip_atomic_store(a.need_tree, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -831,7 +834,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     // buckets of similar list length (longest first) makes the 64 lists of a wave comparable.
     const bool use_grid = s_ctl[1] == 0;
     // diagnostics (nlos_ctx_last_path): this workgroup traces its rays through the in-kernel BVH query
-    if (!use_grid && a.retry && tid == 0 && (TILED || pass > 0)) a.retry[blockIdx.x] = 0x200;   // (first pass, one workgroup per source: at the end)
+    if (!use_grid && a.retry && tid == 0 && (TILED || pass > 0)) a.retry[wgid] = 0x200;   // (first pass, one workgroup per source: at the end)
 #ifdef NLOS_FWD_STAMPS
     if (TILED && tid == 0 && a.dbg && !use_grid && !ident) atomicAdd((unsigned long long*)&a.dbg[20], 1ull);   // entry overflow
     if (TILED && tid == 0 && a.dbg) atomicMax((unsigned long long*)&a.dbg[21], (unsigned long long)s_ctl[2]);
@@ -1449,8 +1452,8 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
         if (tid == 0) vitems[0] = (unsigned long long)n_live | ((unsigned long long)(uint32_t)s_ctl[5] << 16) | ((unsigned long long)(uint32_t)s_ctl[6] << 40);
     }
     if (a.retry && tid == 0) {
-        if (!TILED && pass == 0) a.retry[blockIdx.x] = COARSE ? 0x100 + R : (use_grid ? 0 : 0x200);
-        else if (COARSE) a.retry[blockIdx.x] = 0x100 + R;
+        if (!TILED && pass == 0) a.retry[wgid] = COARSE ? 0x100 + R : (use_grid ? 0 : 0x200);
+        else if (COARSE) a.retry[wgid] = 0x100 + R;
     }
     if (rows_in_lds && grow) {
         __syncthreads();
@@ -1472,7 +1475,7 @@ __global__ __launch_bounds__(kGridNT, kGridNT / 128) void k_forward_grid(Forward
     __shared__ uint32_t s_scan[kGridNT];
     __shared__ uint32_t s_bkt[32];                   // live faces per list-length bucket, then the write cursors
     const int pass = PASS >= 0 ? PASS : pass_arg;
-    if (pass >= 1 && a.retry[blockIdx.x] != pass) return;  // second launch: only the workgroups flagged for it
+    if (pass >= 1 && a.retry[(!TILED && a.perm) ? a.perm[blockIdx.x] : blockIdx.x] != pass) return;  // second launch: only the workgroups flagged for it
     if (!TILED && NCM == 0 && pass == 0) {
         // the chores of the residual launch (ForwardArgs::zero / pathlengths): done here when pass 2 forms the residual itself
         if (a.zero)

@@ -120,6 +120,11 @@ struct nlos_ctx {
     DevBuf geo;                      // pass 1 -> pass 2 geometry cache (h, v, w per ray of the live lists)
     int64_t geo_gen = 0;             // the visibility generation the geometry cache was recorded with (0: none)
     int geo_stride = 0, geo_sources = 0;
+    // pass 1's source order (ForwardArgs::perm): recomputed when the caller's origin array or its length changes -- an array
+    // mutated in place keeps a stale order, which costs time at worst (any permutation renders the same rows)
+    DevBuf src_perm;
+    const float* perm_origin = nullptr;
+    int perm_L = -1;
     DevBuf prod_rec, prod_pairs;     // the product of row N: per-wall-point records; enumerated pairs of the fallback
     int tap_refine = -1, tap_sigma = -1; float tap_res = -1.0f; int tap_kind = -1;
     // host-pointer path staging
@@ -384,9 +389,9 @@ int nlos_env_report(char* buf, int cap) {
     const int n = std::snprintf(tmp, sizeof(tmp),
         "NLOS_TILE_THRESHOLD=%d (6200)\nNLOS_LAZY_TREE=%d (1)\nNLOS_FUSE_RESIDUAL=%d (1)\nNLOS_TILE_TRIS=%d (3000)\n"
         "NLOS_TILE_SCRATCH_MAX=%llu (34359738368)\nNLOS_VIS_ITEMS=%d (1)\nNLOS_GEO_CACHE=%d (1)\nNLOS_GEO_CACHE_MAX_GB=%g (-1)\n"
-        "NLOS_ROW_LDS_MAX=%zu (10240)\nNLOS_GRAD_WIDE=%d (1)\nNLOS_GRAD_MIN_SOURCES=%d (1)\n",
+        "NLOS_ROW_LDS_MAX=%zu (10240)\nNLOS_GRAD_WIDE=%d (1)\nNLOS_GRAD_MIN_SOURCES=%d (1)\nNLOS_FWD_ORDER=%d (1)\n",
         e.tile_threshold, (int)e.lazy_tree, (int)e.fuse_residual, e.tile_tris, e.tile_scratch_max, (int)e.vis_items, (int)e.geo_cache,
-        e.geo_cache_max_gb, e.row_lds_max, e.grad_wide, e.grad_min_sources);
+        e.geo_cache_max_gb, e.row_lds_max, e.grad_wide, e.grad_min_sources, (int)e.fwd_order);
     if (buf && cap > 0) { std::snprintf(buf, (size_t)cap, "%s", tmp); }
     return n;
 }
@@ -424,7 +429,7 @@ void nlos_ctx_destroy(nlos_ctx* c) {
     DeviceGuard g(c->device);
     DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                      &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag, &c->vis_items, &c->prod_rec, &c->prod_pairs, &c->geo};
+                     &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag, &c->vis_items, &c->prod_rec, &c->prod_pairs, &c->geo, &c->src_perm};
     for (DevBuf* b : all) b->release();
     for (DevBuf& b : c->io) b.release();
     for (hipEvent_t& e : c->ring) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
@@ -441,7 +446,7 @@ int64_t nlos_ctx_scratch_bytes(const nlos_ctx* c) {
     if (!c) return 0;
     const DevBuf* all[] = {&c->keys0, &c->keys1, &c->idx0, &c->idx1, &c->child, &c->range, &c->parent, &c->arrive,
                            &c->box, &c->status, &c->nodes, &c->tris, &c->facerec, &c->face_id, &c->tri_zmin, &c->vis, &c->diff,
-                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag, &c->vis_items, &c->prod_rec, &c->prod_pairs, &c->geo};
+                           &c->fine, &c->taps, &c->rows_tmp, &c->grad_tmp, &c->live, &c->reg_normal, &c->reg_area, &c->reg_owner, &c->vis2, &c->tile_list, &c->tile_count, &c->cov, &c->lazy_flag, &c->vis_items, &c->prod_rec, &c->prod_pairs, &c->geo, &c->src_perm};
     int64_t s = 0;
     for (const DevBuf* b : all) s += (int64_t)b->cap;
     for (const DevBuf& b : c->io) s += (int64_t)b.cap;
@@ -643,6 +648,8 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
     fa.force_bvh = (a->force_bvh == 1 || v1_point) ? 1 : 0;
     fa.dbg = nullptr;
     fa.rec_d = fa.rec_ff = nullptr;
+    fa.rec_ext = nullptr; fa.rec_ext_stride = 0;
+    fa.perm = nullptr;
     fa.geo = nullptr; fa.geo_stride = 0; fa.geo_sources = 0;
     // Residual formed by pass 2 itself (round 4): vertex gradient of this call's own forward rows, confocal; k_residual's
     // other chores (clearing the gradient output, the pathlengths) then ride in the grid kernel's first workgroups, and the
@@ -804,6 +811,16 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         } else {
             fa.rows = transient;
         }
+    }
+    // sources in Z-order of the wall (ForwardArgs::perm): one-workgroup-per-source launches of confocal renders and of pairs
+    if (!skip_pass1 && fa.live && !fa.tile_list && L >= 512 && L <= 8192 && nlos::env_switches().fwd_order) {
+        if (c->perm_origin != a->origin || c->perm_L != L) {
+            rc = c->src_perm.ensure(sizeof(int) * (size_t)L + 16);
+            if (rc) return rc;
+            c->perm_origin = nullptr; c->perm_L = -1;
+            if (nlos::launch_order_sources(a->origin, L, c->src_perm.as<int>(), st)) { c->perm_origin = a->origin; c->perm_L = L; }
+        }
+        if (c->perm_origin == a->origin && c->perm_L == L) fa.perm = c->src_perm.as<int>();
     }
     int n_chunks = 0;
     for (int l0 = 0; !skip_pass1 && l0 < L; l0 += chunk_L, ++n_chunks) {

@@ -36,9 +36,12 @@ struct EnvSwitches {
     size_t row_lds_max;                  // NLOS_ROW_LDS_MAX      bytes of histogram row kept in LDS                      (10240)
     int grad_wide;                       // NLOS_GRAD_WIDE        pass 2 may use its wide instance                        (1)
     int grad_min_sources;                // NLOS_GRAD_MIN_SOURCES sources per pass-2 workgroup at least (small L)         (1)
+    bool fwd_order;                      // NLOS_FWD_ORDER        pass 1 takes its sources in Z-order of the wall         (1)
 };
 const EnvSwitches& env_switches();
 void launch_digest_u32(const uint32_t* w, size_t n, unsigned long long* out, hipStream_t stream);
+// perm = the sources in Z-order of their positions (ties: ascending index); false: L beyond what the kernel sorts
+bool launch_order_sources(const float* origin, int L, int* perm, hipStream_t stream);
 inline void note_hip(hipError_t e, const char* what) {
     if (e != hipSuccess && tl_note && tl_note->err == hipSuccess) { tl_note->err = e; tl_note->err_what = what; }
 }
@@ -177,6 +180,12 @@ struct ForwardArgs {
     // rec_d > 0 then means "seen from this wall point" (rec_ff may be 0 there: it is the laser role's form factor).
     float* rec_ext;          // or null (face normals, no albedo: rec_d / rec_ff alone)
     size_t rec_ext_stride;   // floats between two of the seven arrays
+    // Order in which the one-workgroup-per-source launch takes its sources (round 6): blockIdx -> source through `perm`, the
+    // sources sorted along a Z-order curve over their wall positions, so that the ~512 workgroups resident at any time
+    // render a compact patch of the wall instead of eight full rows of it (they then gather the same face records and
+    // finish together: forward 1.348 -> 1.316 ms on the metric, profiles/r06_source_order_probe.log).  Any permutation gives
+    // the same results; null = identity.
+    const int* perm;         // [L] or null
     int* need_tree;          // lazy scene build: raised by first-launch workgroups that need the BVH query (they then leave it to
                              // the second launch, in front of which the tree is completed); null = the tree exists
 };

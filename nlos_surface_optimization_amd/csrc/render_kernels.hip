@@ -240,6 +240,79 @@ __global__ __launch_bounds__(256) void k_digest_u32(const uint32_t* __restrict__
     }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], a); atomicXor(&out[1], b); }
 }
+// One workgroup: bounding box of the source positions, 3 x 10-bit Morton keys, bitonic sort of (key, index) in LDS.
+__device__ __forceinline__ uint32_t spread10(uint32_t x) {
+    x &= 0x3FFu;
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+__global__ __launch_bounds__(1024) void k_order_sources(const float* __restrict__ origin, int L, int n_pad, int* __restrict__ perm) {
+    extern __shared__ unsigned long long s_key[];
+    __shared__ int s_lo[3], s_hi[3];           // ordered-integer images of the floats
+    if (threadIdx.x < 3) { s_lo[threadIdx.x] = 0x7FFFFFFF; s_hi[threadIdx.x] = (int)0x80000000; }
+    __syncthreads();
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = threadIdx.x; i < L; i += blockDim.x)
+        for (int c = 0; c < 3; ++c) { const float x = origin[3 * (size_t)i + c]; lo[c] = fminf(lo[c], x); hi[c] = fmaxf(hi[c], x); }
+    for (int c = 0; c < 3; ++c) {
+        for (int off = 32; off > 0; off >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], off)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], off)); }
+        if ((threadIdx.x & 63) == 0) {
+            // (float min / max through the ordered-integer image: positive and negative values alike)
+            auto enc = [](float f) { const int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7FFFFFFF; };
+            atomicMin(&s_lo[c], enc(lo[c]));
+            atomicMax(&s_hi[c], enc(hi[c]));
+        }
+    }
+    __syncthreads();
+    float blo[3], inv[3];
+    for (int c = 0; c < 3; ++c) {
+        auto dec = [](int b) { return __int_as_float(b >= 0 ? b : b ^ 0x7FFFFFFF); };
+        blo[c] = dec(s_lo[c]);
+        const float ext = dec(s_hi[c]) - blo[c];
+        inv[c] = ext > 0.0f ? 1023.0f / ext : 0.0f;
+    }
+    for (int i = threadIdx.x; i < n_pad; i += blockDim.x) {
+        unsigned long long k = ~0ull;                                   // padding sorts behind every real source
+        if (i < L) {
+            uint32_t q[3];
+            for (int c = 0; c < 3; ++c) {
+                const float t = (origin[3 * (size_t)i + c] - blo[c]) * inv[c];
+                q[c] = (uint32_t)min(max((int)t, 0), 1023);            // (NaN -> 0)
+            }
+            const uint32_t m = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+            k = ((unsigned long long)m << 32) | (unsigned long long)(uint32_t)i;
+        }
+        s_key[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n_pad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n_pad; i += blockDim.x) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long x = s_key[i], y = s_key[p];
+                    const bool asc = (i & k) == 0;
+                    if (asc ? x > y : x < y) { s_key[i] = y; s_key[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < L; i += blockDim.x) perm[i] = (int)(uint32_t)(s_key[i] & 0xFFFFFFFFull);
+}
+bool launch_order_sources(const float* origin, int L, int* perm, hipStream_t stream) {
+    if (L < 2 || L > 8192) return false;
+    int n_pad = 2;
+    while (n_pad < L) n_pad <<= 1;
+    const size_t lds = (size_t)n_pad * sizeof(unsigned long long);
+    note_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_order_sources), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+             "hipFuncSetAttribute(k_order_sources)");
+    hipLaunchKernelGGL(k_order_sources, dim3(1), dim3(1024), lds, stream, origin, L, n_pad, perm);
+    return true;
+}
 void launch_digest_u32(const uint32_t* w, size_t n, unsigned long long* out, hipStream_t stream) {
     note_hip(hipMemsetAsync(out, 0, 16, stream), "hipMemsetAsync(digest)");
     hipLaunchKernelGGL(k_digest_u32, dim3(1024), dim3(256), 0, stream, w, n, out);
@@ -264,6 +337,7 @@ const EnvSwitches& env_switches() {
         s.row_lds_max = (size_t)geti("NLOS_ROW_LDS_MAX", 10 * 1024);
         s.grad_wide = (int)geti("NLOS_GRAD_WIDE", 1);
         s.grad_min_sources = (int)geti("NLOS_GRAD_MIN_SOURCES", 1);
+        s.fwd_order = geti("NLOS_FWD_ORDER", 1) != 0;
         return s;
     }();
     return e;

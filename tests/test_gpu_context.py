@@ -381,3 +381,34 @@ def test_geometry_cache_is_bounded_and_optional():
     out = subprocess.run([sys.executable, os.path.join(root, "__graft_entry__.py"), "smoke"], capture_output=True, text=True,
                          env=e, timeout=600)
     assert out.returncode == 0 and "smoke: transient rel-L2" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_source_order_does_not_change_results_and_follows_the_origin_array(bunny, orc):
+    """Round 6: pass 1 takes its sources in Z-order of their wall positions (a cached permutation, recomputed when the origin
+    array or its length changes).  Rows belong to their sources whatever the order; a different origin array of the same
+    length, a shuffled one, and wall positions that are all negative must all render the oracle's rows."""
+    import torch
+    from nlos_surface_optimization_amd import device as nd
+    from conftest import grid_sources
+    v, f = bunny
+    dev = torch.device("cuda", 0)
+    r = nd.TransientRenderer(dev, seed=0)
+    tv, tf = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
+    o, n = grid_sources(24, 0.25)                                   # 576 sources (>= 512: the order is used)
+    rs = np.random.RandomState(3)
+    for name, oo in (("grid", o), ("shuffled", o[rs.permutation(o.shape[0])]), ("negative", o - np.array([0.6, 0.5, 0], np.float32))):
+        oo = np.ascontiguousarray(oo, np.float32)
+        to, tn = torch.from_numpy(oo).to(dev), torch.from_numpy(n).to(dev)
+        t, _ = r.render_transient(to, tn, tv, tf, 20000, 0.625, 1.625, 2.0 ** -9)
+        sel = rs.choice(oo.shape[0], 12, replace=False)
+        t_ref, _ = orc.render_transient(oo, n, v, f, 20000, 0.625, 1.625, 2.0 ** -9, accel=1, seed=0)
+        assert rel_l2(t.cpu().numpy(), t_ref) <= 1e-12, name
+        assert rel_l2(t.cpu().numpy()[sel], t_ref[sel]) <= 1e-12, name
+        # the same array again (cached order), then mutated in place (stale order: still every source's own row)
+        t2, _ = r.render_transient(to, tn, tv, tf, 20000, 0.625, 1.625, 2.0 ** -9)
+        assert rel_l2(t2.cpu().numpy(), t_ref) <= 1e-12, name
+        to.copy_(torch.flip(to, [0]))
+        t3, _ = r.render_transient(to, tn, tv, tf, 20000, 0.625, 1.625, 2.0 ** -9)
+        t_ref3, _ = orc.render_transient(np.ascontiguousarray(oo[::-1]), n, v, f, 20000, 0.625, 1.625, 2.0 ** -9, accel=1, seed=0)
+        assert rel_l2(t3.cpu().numpy(), t_ref3) <= 1e-12, name
+    r.close()
