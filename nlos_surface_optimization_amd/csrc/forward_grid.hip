@@ -372,7 +372,7 @@ __global__ __launch_bounds__(512) void k_tile_bin(ForwardArgs a, int R, int from
 // tried: a few heavy workgroups fill the chip badly -- 4.4 vs 3.2 ms where a third of the sources overflow.)
 template <int FEAT, int NCM, bool TILED, bool COARSE>
 __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_in_lds, const int R_launch, const int cap, const int pass,
-                                          const int last_pass, uint32_t* s_scan, uint32_t* s_bkt) {
+                                          const int last_pass, uint32_t* s_scan, uint32_t* s_bkt, const unsigned slot) {
     constexpr int kCoarsen = COARSE ? NLOS_MAX_COARSEN : 0;
     // R_launch fixes the LDS layout; the grid actually used (R, R2, ncell) may be coarsened below when the
     // cell lists of this source do not fit
@@ -390,7 +390,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     int R2 = (R + 1) >> 1;
     const int F = a.sc.F;
     const int ntiles = TILED ? a.tiles_x * a.tiles_y : 1;
-    const int tile = TILED ? (int)(blockIdx.x % (unsigned)ntiles) : 0;
+    const int tile = TILED ? (int)(slot % (unsigned)ntiles) : 0;       // (TILED: wgid == slot == blockIdx.x)
     const int tile_x = TILED ? tile % a.tiles_x : 0, tile_y = TILED ? tile / a.tiles_x : 0;
     const int mask_blocks = TILED ? (a.tile_cap + 63) >> 6 : (F + 63) >> 6;   // LDS sizing only (tiles that visit all faces keep no masks)
     uint32_t* s_cell = reinterpret_cast<uint32_t*>(s_row + (rows_in_lds ? nbins : 0));
@@ -410,7 +410,8 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     // 2.29 ms instead of 1.91 ms.)
     // (one workgroup per source: the source this workgroup renders, in the launcher's order when it has one -- wgid replaces
     // blockIdx.x everywhere below; the tiled grid keeps its (source, tile) numbering)
-    const unsigned wgid = (!TILED && a.perm) ? (unsigned)a.perm[blockIdx.x] : blockIdx.x;
+    // `slot`: blockIdx.x
+    const unsigned wgid = (!TILED && a.perm) ? (unsigned)a.perm[slot] : slot;
     uint16_t* g_live = a.live + (size_t)wgid * (TILED ? a.tile_cap : F);
     uint16_t* g_cov = a.cov + (size_t)wgid * (TILED ? a.tile_cap : F);     // per-triangle cell coverage, count -> fill pass
     uint32_t* tl = TILED ? a.tile_list + (size_t)wgid * a.tile_cap : nullptr;
@@ -714,6 +715,7 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             const int c0 = min(tid * per, ncell), c1 = min(c0 + per, ncell);
             uint32_t sum = 0;
             for (int c = c0; c < c1; ++c) sum += s_cell[c];
+#ifdef NLOS_DIAG_HS_SCAN             // diagnostic builds only: round 1's Hillis-Steele scan over the workgroup (20 barriers)
             s_scan[tid] = sum;
             __syncthreads();
             for (int off = 1; off < NT; off <<= 1) {
@@ -722,6 +724,23 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 s_scan[tid] += v;
                 __syncthreads();
             }
+#else
+            // inclusive scan of the per-thread sums: within the wave by lane shuffles, across the waves through their
+            // totals in LDS (round 6: 2 barriers instead of 20)
+            uint32_t incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off);
+                if (lane >= off) incl += up;
+            }
+            if (lane == 63) s_scan[wave] = incl;
+            __syncthreads();
+            uint32_t base = 0u;
+            for (int wv = 0; wv < wave; ++wv) base += s_scan[wv];
+            __syncthreads();
+            s_scan[tid] = incl + base;                       // (tid NT - 1 reads the grand total below)
+            __syncthreads();
+#endif
             uint32_t run = s_scan[tid] - sum;
             for (int c = c0; c < c1; ++c) {
                 uint32_t n = s_cell[c];
@@ -1483,9 +1502,13 @@ __global__ __launch_bounds__(kGridNT, kGridNT / 128) void k_forward_grid(Forward
         if (a.pathlengths && blockIdx.x == 0)
             for (int i = threadIdx.x; i < a.path_T; i += kGridNT) a.pathlengths[i] = (double)(a.path_lb + i * a.path_res);
     }
-    if (grid_body<FEAT, NCM, TILED, false>(a, rows_in_lds, R, cap, pass, last_pass, s_scan, s_bkt)) {
+    // (Round 6, built, measured, removed: PERSISTENT workgroups -- 2 per CU drawing sources from a self-resetting device ticket,
+    // no workgroup dispatch between two sources of a CU.  The loop around the body costs the kernel its register allocation:
+    // 85 - 120 VGPR + 304 - 404 SGPR spills instead of 17 + 125, forward 1.29 -> 1.84 ms; a non-inlined body moves the spills
+    // into the callee (scratch 572 B).  profiles/r06_ab_persistent_scan.log.)
+    if (grid_body<FEAT, NCM, TILED, false>(a, rows_in_lds, R, cap, pass, last_pass, s_scan, s_bkt, blockIdx.x)) {
         __syncthreads();
-        grid_body<FEAT, NCM, TILED, true>(a, rows_in_lds, R, cap, pass, last_pass, s_scan, s_bkt);
+        grid_body<FEAT, NCM, TILED, true>(a, rows_in_lds, R, cap, pass, last_pass, s_scan, s_bkt, blockIdx.x);
     }
 }
 
