@@ -784,7 +784,10 @@ def run_rank(args, backend):
                                   "note": "exceeds peak where > 1: a model of the reference's traffic, not of this path's"}
             # the ceiling that binds the dominant kernel, first-class: VALU issue slots used / available (central estimate of
             # the weighted issue model, profiles/pmc_summary.json of THIS build; None when the committed counters are stale)
-            roof["valu_issue_frac"] = (issue or {}).get("valu_busy", {}).get("central") if isinstance((issue or {}).get("valu_busy"), dict) else None
+            # (round 6: priced with the instruction costs measured inside this kernel where the profile carries them --
+            # `issue.valu_busy_in_situ`; `issue.valu_busy` keeps the back-to-back costs of rounds 3-5 for comparison)
+            vb = (issue or {}).get("valu_busy_in_situ") or (issue or {}).get("valu_busy")
+            roof["valu_issue_frac"] = vb.get("central") if isinstance(vb, dict) else None
             pmc_all = load_pmc_summary() or {}
             g2 = pmc_all.get("k_gradient") if traffic else None
             if g2 and kt[3] > 0:
@@ -799,6 +802,11 @@ def run_rank(args, backend):
             if traffic:
                 roof["profile_stamp"] = pmc_stamp
             out["roofline"] = roof
+        try:      # every behaviour-changing environment switch as this process read it (nlos_env_report)
+            from nlos_surface_optimization_amd import _lib as _nl2
+            out["env"] = _nl2.env_report()
+        except Exception:
+            pass
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         print(json.dumps(out))

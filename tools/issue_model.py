@@ -86,6 +86,30 @@ def main():
                   % (N_SIMD, CLOCK / 1e9, "measured on the forward kernel: s_memtime / s_memrealtime, tools/build_stamps.sh"
                      if "NLOS_CLOCK_GHZ" in os.environ else "peak: a lower bound on busy")),
     }
+    # Round 6: the same accounting with IN-SITU costs (tools/insitu_costs.py, profiles/r06_insitu_costs.json): what one more
+    # instruction of a class costs this very kernel at three of its sites.  Back to back a "half-rate" instruction holds the SIMD
+    # for 4.1 cycles; inside the kernel's mix it costs 2.1 - 2.9 (it overlaps with other waves' full-rate instructions), a
+    # full-rate one 1.3 - 2.3.  central: class means of the trace sites, the build phases' share of the instructions (NLOS_BUILD_SHARE,
+    # default 0.38) at the counting pass's discount; lo / hi: every class at its cheapest / dearest measured cost and the
+    # unclassified instructions all full / all half rate.
+    insitu = os.environ.get("NLOS_INSITU_JSON", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r06_insitu_costs.json"))
+    if os.path.exists(insitu) and prefix.startswith("k_forward_grid"):
+        t = json.load(open(insitu))
+        trace = [c for c in t["costs"] if c["site"] in ("WALK", "GEN")]
+        build = [c for c in t["costs"] if c["site"] == "COUNT"]
+        fu = [c["cycles_per_instruction"] for c in trace if c["back_to_back"] == 2.3]
+        ha = [c["cycles_per_instruction"] for c in trace if c["back_to_back"] == 4.1]
+        mean = lambda v: sum(v) / len(v)
+        disc = mean([c["cycles_per_instruction"] / (mean(fu) if c["back_to_back"] == 2.3 else mean(ha)) for c in build])
+        share = float(os.environ.get("NLOS_BUILD_SHARE", "0.38"))
+        scale = (1.0 - share) + share * disc
+        tr_lo, tr_hi = QUARTER * min(min(ha) / HALF, 1.0), QUARTER        # transcendentals were not padded: scaled like the half-rate class
+        cyc2 = lambda cf, ch, ct, ff: f32 * cf + trans * ct + half_known * ch + mixed * (ff * cf + (1 - ff) * ch)
+        out["valu_busy_in_situ"] = {"lo": cyc2(min(fu), min(ha), tr_lo, 1.0) * scale / denom,
+                                    "central": cyc2(mean(fu), mean(ha), 0.5 * (tr_lo + tr_hi), frac_full) * scale / denom,
+                                    "hi": cyc2(max(fu), max(ha), tr_hi, 0.0) / denom}
+        out["in_situ_costs"] = {"full_rate_trace": [min(fu), mean(fu), max(fu)], "half_rate_trace": [min(ha), mean(ha), max(ha)],
+                                "build_discount": disc, "build_share_of_instructions": share, "source": os.path.basename(insitu)}
     print(json.dumps(out, indent=1))
 
 

@@ -83,6 +83,9 @@ if dur_ms:
                              "issuing": fw["SQ_ACTIVE_INST_ANY"] / fw["SQ_WAVE_CYCLES"]},
         "valu_insts_per_launch": fw["SQ_INSTS_VALU"], "salu_insts_per_launch": fw["SQ_INSTS_SALU"],
         "lds_insts_per_launch": fw["SQ_INSTS_LDS"], "vmem_insts_per_launch": fw["SQ_INSTS_VMEM"],
+        # round 6: the busy figure re-priced with the instruction costs measured INSIDE this kernel (tools/pad_test.sh), and the
+        # marginal cost itself -- what removing one instruction gives back
+        "valu_busy_in_situ": m.get("valu_busy_in_situ"), "in_situ_costs": m.get("in_situ_costs"),
         "classes": m["classes"], "mixed_full_rate_fraction": m["mixed_full_rate_fraction"],
         "basis": m["basis"] + "; kernel " + fw_name}
 if gr:
