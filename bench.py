@@ -511,7 +511,7 @@ def run_rank(args, backend):
     # pairs, forward-only or with the gradient, whatever the mesh); the flags are MIN-all-reduced, so a result line
     # means every GPU passed.  On rank 0 at N = 1 the CPU leg doubles as the reported baseline. ----
     plain = (not (args.forward_only or args.non_confocal or args.subdivide or args.faces or args.of > 1) and args.mesh == "bunny_5k"
-             and args.config == "metric" and args.grid == 64 and args.bins == 512)
+             and args.config == "metric")
     parity, cpu_base = None, None
     budget = 15.0 if (world == 1 and plain and not args.no_cpu_baseline) else 0.0
     data_np = data.cpu().numpy()
@@ -643,7 +643,7 @@ def run_rank(args, backend):
     # ---- the paths a user of the reference's API calls (round 6): the numpy drop-in (host arrays in, host arrays out, every
     # call: transient_rendering_cython/main.py:114-115, exp_bunny/rendering.py:252-269) and the autograd pair ----
     api_paths = None
-    if world == 1 and plain and args.dropin_steps > 0 and not diagnostic:
+    if world == 1 and plain and args.dropin_steps > 0 and not diagnostic and backend.name == "nccl":     # (a real GPU rank)
         api_paths = time_api_paths(args, r, backend, origin_np, normal_np, v_np, f_np, data_np, lb, ub, res, T,
                                    origin, normal, verts, faces, data, weight, grad)
 
