@@ -214,32 +214,20 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
 #ifndef NLOS_GRAD_LOOKAHEAD
 #define NLOS_GRAD_LOOKAHEAD 1
 #endif
-        // Block lookahead (round 6, item-mask layout without compaction): ticket -> live-list entry -> item masks -> face record
-        // -> first geometry record are dependent round trips in front of a block's arithmetic, and four waves per SIMD do not
-        // hide them.  The ticket, the entry's face slot and its accepted-sample bits of the NEXT block are requested behind this
-        // block's face-record loads (three registers across the block).
-        const bool ahead = NLOS_GRAD_LOOKAHEAD && skip_compact;
-#ifndef NLOS_GRAD_LOOKAHEAD_GEO
-#define NLOS_GRAD_LOOKAHEAD_GEO 1
-#endif
-        // (GEO: also the first geometry record of the next block's entry -- the one load that comes from HBM)
-        constexpr bool kAheadGeo = GEO && NLOS_GRAD_LOOKAHEAD_GEO;
+        // Block lookahead (round 6; the geometry-cache instance of Lambertian renders): ticket -> live-list entry -> item masks ->
+        // face record -> first geometry record are dependent round trips in front of a block's arithmetic, and four waves per
+        // SIMD do not hide them.  The ticket, the entry's face slot and its accepted-sample bits of the NEXT block are requested
+        // behind this block's face-record loads (three registers across the block): metric pass 2 0.353 -> 0.348 ms, 32 x 32
+        // sources 0.106 -> 0.103 ms.  Measured and NOT enabled elsewhere (profiles/r06_ab_grad_lookahead.log): the regenerating
+        // instance loses (mannequin 0.638 -> 0.661 ms: its registers are worth more), the GGX one is even (0.674 -> 0.678);
+        // requesting the next block's first geometry record as well (six more registers, 7 spilled) loses everywhere (0.358).
+        const bool ahead = NLOS_GRAD_LOOKAHEAD && skip_compact && GEO && !(FEAT & FEAT_GGX);
         int b_nx = 0, j_nx = 0;
         uint32_t ib_nx = 0u;
-        f4_t rec_nx = {0.0f, 0.0f, 0.0f, 0.0f};
-        f2_t w_nx = {0.0f, 0.0f};
         auto fetch_next = [&]() {
             b_nx = wave_ticket(s_next);
             const int li1 = (b_nx << 6) + lane;
-            if (b_nx < live_blocks && li1 < n_live) {
-                j_nx = (int)live_l[li1];
-                ib_nx = item_bits(it_l, li1, spt);
-                if (kAheadGeo && ib_nx) {
-                    const size_t at1 = (size_t)(__ffs(ib_nx) - 1) * (size_t)F + (size_t)li1;
-                    rec_nx = __builtin_nontemporal_load(geo_l + at1);
-                    w_nx = __builtin_nontemporal_load(geo_w + at1);
-                }
-            }
+            if (b_nx < live_blocks && li1 < n_live) { j_nx = (int)live_l[li1]; ib_nx = item_bits(it_l, li1, spt); }
         };
         if (ahead) fetch_next();
         for (;;) {
@@ -250,8 +238,6 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
             const int e = (a.compact && !skip_compact) ? (has ? (int)s_live[li] : 0) : li;   // a face slot, or (item masks) an entry of the live list
             const int j = ahead ? j_nx : ((it_l && has) ? (int)live_l[e] : e);
             const uint32_t ibits = ahead ? ib_nx : ((it_l && has) ? item_bits(it_l, e, spt) : 0u);
-            const f4_t rec_first = rec_nx;
-            const f2_t w_first = w_nx;
             Face f;
             Tri tr;
             if (has) load_face_tri<FEAT | FEAT_VN>(a.sc, j, f, tr);    // vertices, ids, and the per-face constants the scene build evaluated
@@ -271,9 +257,7 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                 // sample in front of its arithmetic left the kernel waiting: 0.558 -> 0.503 ms only, profiles/r04_ab_geo_cache.log)
                 f4_t nrec = {0.0f, 0.0f, 0.0f, 0.0f};
                 f2_t nw = {0.0f, 0.0f};
-                if (kAheadGeo && ahead) {
-                    nrec = rec_first; nw = w_first;                 // requested one block ahead
-                } else if (GEO && word) {
+                if (GEO && word) {
                     const size_t at = (size_t)(__ffs(word) - 1) * (size_t)F + (size_t)e;      // [stratum][live-list entry]
                     nrec = __builtin_nontemporal_load(geo_l + at);
                     nw = __builtin_nontemporal_load(geo_w + at);
