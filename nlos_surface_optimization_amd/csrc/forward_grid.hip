@@ -1095,10 +1095,15 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                         const size_t at = (size_t)s * (size_t)F + (size_t)li;
                         f4_t* gp = reinterpret_cast<f4_t*>(geo_l) + at;
                         const f4_t rec = {gg.dir.x, gg.dir.y, gg.dir.z, gg.v};
-                        __builtin_nontemporal_store(rec, gp);
                         typedef float f2_t __attribute__((ext_vector_type(2)));
                         const f2_t rec2 = {gg.w, gg.h};
+#ifdef NLOS_GEO_CACHED_STORES          // diagnostic builds only: write-back stores (many strata per face: the pieces of a line merge in the L2)
+                        *gp = rec;
+                        *(reinterpret_cast<f2_t*>(geo_w) + at) = rec2;
+#else
+                        __builtin_nontemporal_store(rec, gp);
                         __builtin_nontemporal_store(rec2, reinterpret_cast<f2_t*>(geo_w) + at);
+#endif
                     }
                 }
             } else if (NCM == 3) {

@@ -292,9 +292,34 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                     float t_self;
                     if (GEO) {
                         cached_geo<FEAT>(f, cdir, cv, cw, ch, a.sc.vertex_normal, a.sc.albedo, g);
-                    } else if (!sample_geo_keyed<FEAT>(f, tr, o, zbase, (uint32_t)f.fid * (uint32_t)spt + (uint32_t)s, lean_src, a.sp.lb, a.sp.ub,
-                                                       a.sc.vertex_normal, a.sc.albedo, g, t_self))
+                    }
+#ifdef NLOS_DIAG_GRAD_FREE_VWH      // diagnostic builds only (results are wrong): what a 12-byte (v, w, h) record from pass 1 could
+                                    // save the regenerating pass 2 at most -- the draw and the sampled direction stay, the own-face
+                                    // test, the hit point and its square root are free (tools: --diagnostic-no-gate)
+                    else {
+                        float S_, T_;
+                        sample_st_c(zbase, (uint32_t)f.fid * (uint32_t)spt + (uint32_t)s, S_, T_);
+                        const float sq_ = sqrt_cr0(T_);
+                        g.u = 1 - sq_; g.v = (1 - S_) * sq_; g.w = S_ * sq_;
+                        const V3 p_ = bary(g.u, f.p0, g.v, f.p1, g.w, f.p2);
+                        const V3 d_ = p_ - o;
+                        const float dd_ = dot(d_, d_);
+                        const float rs_ = rcp_cr(sqrt_cr(dd_));
+                        g.dir = d_ * rs_;
+                        g.h = dd_ * rs_;
+                        g.n = f.fn;
+                        if (FEAT & FEAT_VN)
+                            g.n = bary(g.u, ld3(a.sc.vertex_normal + 3 * (size_t)f.i0), g.v, ld3(a.sc.vertex_normal + 3 * (size_t)f.i1), g.w,
+                                       ld3(a.sc.vertex_normal + 3 * (size_t)f.i2));
+                        g.alb = 1.0f;
+                        if (FEAT & FEAT_ALB) g.alb = g.u * a.sc.albedo[f.i0] + g.v * a.sc.albedo[f.i1] + g.w * a.sc.albedo[f.i2];
+                        t_self = 0.0f;
+                    }
+#else
+                    else if (!sample_geo_keyed<FEAT>(f, tr, o, zbase, (uint32_t)f.fid * (uint32_t)spt + (uint32_t)s, lean_src, a.sp.lb, a.sp.ub,
+                                                     a.sc.vertex_normal, a.sc.albedo, g, t_self))
                         continue;   // cannot happen: pass 1 accepted this sample with the same arithmetic
+#endif
                     const double twoh = (double)(2.0f * g.h);
                     if (MODE == 1 || MODE == 2) {
                         // rows A / GGX alpha: scalar gradients (literal tap loop, double weights)

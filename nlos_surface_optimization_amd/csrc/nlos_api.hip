@@ -389,9 +389,9 @@ int nlos_env_report(char* buf, int cap) {
     const int n = std::snprintf(tmp, sizeof(tmp),
         "NLOS_TILE_THRESHOLD=%d (6200)\nNLOS_LAZY_TREE=%d (1)\nNLOS_FUSE_RESIDUAL=%d (1)\nNLOS_TILE_TRIS=%d (3000)\n"
         "NLOS_TILE_SCRATCH_MAX=%llu (34359738368)\nNLOS_VIS_ITEMS=%d (1)\nNLOS_GEO_CACHE=%d (1)\nNLOS_GEO_CACHE_MAX_GB=%g (-1)\n"
-        "NLOS_ROW_LDS_MAX=%zu (10240)\nNLOS_GRAD_WIDE=%d (1)\nNLOS_GRAD_MIN_SOURCES=%d (1)\nNLOS_FWD_ORDER=%d (1)\n",
+        "NLOS_ROW_LDS_MAX=%zu (10240)\nNLOS_GRAD_WIDE=%d (1)\nNLOS_GRAD_MIN_SOURCES=%d (1)\nNLOS_FWD_ORDER=%d (1)\nNLOS_GEO_MAX_SPT=%d (8)\n",
         e.tile_threshold, (int)e.lazy_tree, (int)e.fuse_residual, e.tile_tris, e.tile_scratch_max, (int)e.vis_items, (int)e.geo_cache,
-        e.geo_cache_max_gb, e.row_lds_max, e.grad_wide, e.grad_min_sources, (int)e.fwd_order);
+        e.geo_cache_max_gb, e.row_lds_max, e.grad_wide, e.grad_min_sources, (int)e.fwd_order, e.geo_max_spt);
     if (buf && cap > 0) { std::snprintf(buf, (size_t)cap, "%s", tmp); }
     return n;
 }
@@ -761,7 +761,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
             // (spt <= 8 only: a 64-ray item writes spt segments of 64 / spt consecutive records; at spt = 19 -- the 1 055-face
             // mannequin -- those are 54-byte pieces, and the streaming stores of partial lines triple pass 1: 1.09 -> 2.80 ms,
             // profiles/r04_side_bench.log; such renders keep the recomputing pass 2)
-            if (geo_enabled && spt <= 8 && !a->sensor && !jitter && (mode == NLOS_MODE_GRADIENT || mode == NLOS_MODE_GRADIENT_V1 || mode == NLOS_MODE_TRANSIENT)) {
+            if (geo_enabled && spt <= nlos::env_switches().geo_max_spt && !a->sensor && !jitter && (mode == NLOS_MODE_GRADIENT || mode == NLOS_MODE_GRADIENT_V1 || mode == NLOS_MODE_TRANSIENT)) {
                 // an optimisation, never a reason to fail: bounded -- NLOS_GEO_CACHE_MAX_GB if set, else 32 GB or half of what
                 // the device has free, whichever is less -- and skipped when the allocation does not succeed (pass 2 then
                 // regenerates its samples).  DevBuf::try_ensure: exact size, the old buffer survives a failed growth, the

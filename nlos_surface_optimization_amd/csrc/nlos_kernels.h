@@ -37,6 +37,7 @@ struct EnvSwitches {
     int grad_wide;                       // NLOS_GRAD_WIDE        pass 2 may use its wide instance                        (1)
     int grad_min_sources;                // NLOS_GRAD_MIN_SOURCES sources per pass-2 workgroup at least (small L)         (1)
     bool fwd_order;                      // NLOS_FWD_ORDER        pass 1 takes its sources in Z-order of the wall         (1)
+    int geo_max_spt;                     // NLOS_GEO_MAX_SPT      strata per face up to which pass 1 records the geometry cache (8)
 };
 const EnvSwitches& env_switches();
 void launch_digest_u32(const uint32_t* w, size_t n, unsigned long long* out, hipStream_t stream);

@@ -338,6 +338,7 @@ const EnvSwitches& env_switches() {
         s.grad_wide = (int)geti("NLOS_GRAD_WIDE", 1);
         s.grad_min_sources = (int)geti("NLOS_GRAD_MIN_SOURCES", 1);
         s.fwd_order = geti("NLOS_FWD_ORDER", 1) != 0;
+        s.geo_max_spt = (int)geti("NLOS_GEO_MAX_SPT", 8);
         return s;
     }();
     return e;
