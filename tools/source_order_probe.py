@@ -40,3 +40,8 @@ for rep in range(2):
     blk = np.argsort((y // 16) * 4096 + (x // 32) * 1024 + (y % 16) * 32 + (x % 32), kind="stable")
     run(blk, "32x16 blocks, row-major")
     run(np.argsort(x * 64 + y, kind="stable"), "column-major")
+    # workgroup i runs on XCD i % 8: hand every XCD its own contiguous eighth of the Z-order curve
+    k = np.arange(L)
+    run(mort[(k % 8) * (L // 8) + k // 8], "Morton, one eighth of the curve per XCD")
+    run(idx[(k % 8) * (L // 8) + k // 8], "row-major, one eighth per XCD")
+    hil = None
