@@ -5,6 +5,7 @@ product fails loudly (no CPU fallback, no oracle import) when no GPU is present.
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -174,3 +175,46 @@ def test_bench_contract_helpers_run_without_a_gpu():
         w = bench.workload_config(b, 32, b.bins, 1000, 500, 4, 1024, 1)["workload"]
         assert ("side measurement" in w) == (flags[0] in ("--non-confocal", "--subdivide", "--faces"))
     assert bench.METRIC.startswith("surface samples/sec fwd+grad")
+
+
+def test_environment_switches_are_listed_with_their_defaults():
+    """Round 6: one accessor reads every behaviour-changing environment switch once per process; nlos_env_report lists them.
+    Run in a child process with two of them set, so that this process's own (already read) values do not matter."""
+    code = ("import json; from nlos_surface_optimization_amd import _lib; print(json.dumps(_lib.env_report()))")
+    env = dict(os.environ)
+    for k in list(env):
+        if k.startswith("NLOS_"):
+            del env[k]
+    env["NLOS_ROW_LDS_MAX"] = "4096"
+    env["NLOS_FWD_ORDER"] = "0"
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1000:]
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    want = {"NLOS_TILE_THRESHOLD": "6200", "NLOS_LAZY_TREE": "1", "NLOS_FUSE_RESIDUAL": "1", "NLOS_TILE_TRIS": "3000", "NLOS_VIS_ITEMS": "1",
+            "NLOS_GEO_CACHE": "1", "NLOS_GEO_CACHE_MAX_GB": "-1", "NLOS_ROW_LDS_MAX": "4096", "NLOS_GRAD_WIDE": "1", "NLOS_GRAD_MIN_SOURCES": "1",
+            "NLOS_FWD_ORDER": "0", "NLOS_GEO_MAX_SPT": "8"}
+    for k, v in want.items():
+        assert rep.get(k) == v, (k, rep.get(k))
+    assert int(rep["NLOS_TILE_SCRATCH_MAX"]) == 32 << 30
+
+
+def test_bench_config_presets_name_the_baseline_configurations():
+    """bench.py --config: the presets of BASELINE.json's configurations and of the reference's experiment shape."""
+    import bench
+    a = bench.parse_args([])
+    assert (a.config, a.grid, a.bins, a.mesh, a.half, a.res_m, a.alpha) == ("metric", 64, 512, "bunny_5k", 0.25, None, None)
+    a = bench.parse_args(["--config", "2"])
+    assert a.grid == 32 and a.forward_only and a.bins == 512
+    a = bench.parse_args(["--config", "4"])
+    assert (a.mesh, a.bins, a.half, a.lb, a.res_m, a.measurement) == ("mannequin", 1024, 0.35, 0.0, 2.4e-3, True)
+    a = bench.parse_args(["--config", "4pairs"])
+    assert a.non_confocal and not a.measurement and a.mesh == "mannequin"
+    a = bench.parse_args(["--config", "5"])
+    assert a.alpha == 0.3 and a.poisson and a.bins == 1024
+    a = bench.parse_args(["--config", "exp"])
+    assert (a.bins, a.lb, a.res_m) == (1200, 0.0, 1.2e-3)
+    from nlos_surface_optimization_amd import _lib
+    assert _lib.num_bins(0.0, 1200 * 1.2e-3, 1.2e-3) == 1200       # the window the reference's scripts pass gives their 1200 bins
+    assert a.sustain_seconds == 6.0
