@@ -423,6 +423,47 @@ __device__ __forceinline__ float ggx_eval_nwsdiff(float a, float nw) {
 }
 
 
+// Pass 2's forms of the same functions (round 6).  Pass 2 decides nothing -- the sample was accepted by pass 1 and its bins come from
+// pass 1's h -- so its gradient VECTORS may use the 1-ulp reciprocal and square root and single precision throughout (DESIGN.md
+// section 2, as the Lambertian branch has since round 3): ggx_D() above divides in DOUBLE (NLOS_PI is one) and the *_ndiff
+// functions hold three IEEE divisions and a square root each -- about 250 of the GGX sample loop's instructions.  The values move by
+// ~1e-7 relative, the gradient tolerance is 1e-4.  Early-outs and the 1e-20 cut as above.
+__device__ __forceinline__ float ggx_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float ggx_D_fast(float a, float nw) {
+    if (nw <= 0) return 0.0f;
+    const float nw2 = nw * nw, a2 = a * a;
+    const float root = nw2 + (1.0f - nw2) * ggx_rcp(a2);            // (1 + (1 - nw2) / a2 / nw2) nw2
+    float result = ggx_rcp(3.14159265358979323846f * a2 * root * root);
+    if (result * nw < 1e-20f) result = 0;
+    return result;
+}
+__device__ __forceinline__ float ggx_G1_fast(float a, float nw, float& temp_out) {
+    temp_out = __builtin_amdgcn_sqrtf(a * a + (1.0f - a * a) * nw * nw);
+    if (nw <= 0) return 0.0f;
+    if ((nw >= 1.0f) || (nw <= -1.0f)) return 1.0f;
+    return 2.0f * ggx_rcp(nw + temp_out);
+}
+// brdf = ggx_eval, s = ggx_eval_nwsdiff, sharing D, G1 and the square root
+__device__ __forceinline__ void ggx_eval_and_nwsdiff_fast(float a, float nw, float& brdf, float& s) {
+    brdf = 0.0f; s = 0.0f;
+    if (nw <= 0) return;
+    const float Dv = ggx_D_fast(a, nw);
+    if (Dv == 0) return;
+    float temp;
+    const float G1 = ggx_G1_fast(a, nw, temp);
+    const float Gv = G1 * G1;
+    brdf = Dv * Gv * 0.25f;
+    const float a2 = a * a;
+    float G1n = 0.0f;
+    if (!((nw >= 1.0f) || (nw <= -1.0f))) {
+        const float ir = ggx_rcp(nw + temp);
+        G1n = -2.0f * (1.0f - (nw * (a2 - 1.0f)) * ggx_rcp(temp)) * (ir * ir);
+    }
+    const float root = (a2 - 1.0f) * nw * nw + 1.0f;
+    const float Dp = -(4.0f * a2 * nw * (a2 - 1.0f)) * ggx_rcp(3.14159265358979323846f * root * root * root);
+    s = (Dp * Gv + (2.0f * G1n * G1) * Dv) * 0.25f;
+}
+
 // GGX for a (laser, sensor) pair (row N with the GGX branch; the reference has neither a kernel nor a prototype):
 // the half-vector form of the same microfacet model,
 //     brdf(n, wa, wb) = D(n.h) G1(n.wa) G1(n.wb) / 4,   h = (wa + wb) / |wa + wb|,

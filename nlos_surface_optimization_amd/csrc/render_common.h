@@ -310,24 +310,36 @@ __device__ __forceinline__ void grad_vectors(const Face& f, const Geo& g, V3 on,
     const float h2 = g.h * g.h;
     V3 t1, gn = mk(0, 0, 0);
     if (FEAT & FEAT_GGX) {
-        // (the GGX branch keeps the contract's divisions: its factors are shared with the scalar alpha gradient)
+#ifdef NLOS_DIAG_GGX_IEEE            // diagnostic builds only: the contract's divisions (rounds 1 - 5)
         const float ff = c2 * c3 / g.h / g.h;
         const float h4 = h2 * h2, h5 = h4 * g.h;
-        const V3 inner = ((on * c3) - (g.n * c2)) + ((((-g.dir) * 4.0f) * c2) * c3);
+        const float ih = 1.0f / g.h, ih5 = 1.0f / h5, ih4 = 1.0f / h4;
         V3 wv = -g.dir;
         float nw = dot(g.n, wv);
         float brdf = ggx_eval(alpha, nw);
         float s = ggx_eval_nwsdiff(alpha, nw);
+#else
+        // (round 6: non-decision arithmetic like the Lambertian branch -- 1-ulp reciprocals, the BRDF and its derivative from
+        // one evaluation in single precision, nlos_device.h: ggx_eval_and_nwsdiff_fast)
+        const float ih = rcp_fast(g.h), ih2 = ih * ih;
+        const float ff = (c2 * c3) * ih2;
+        const float ih4 = ih2 * ih2, ih5 = ih4 * ih;
+        V3 wv = -g.dir;
+        float nw = dot(g.n, wv);
+        float brdf, s;
+        ggx_eval_and_nwsdiff_fast(alpha, nw, brdf, s);
+#endif
+        const V3 inner = ((on * c3) - (g.n * c2)) + ((((-g.dir) * 4.0f) * c2) * c3);
         V3 dn = wv * s, dw = g.n * s;
-        V3 dx = (-dw) + ((g.dir * dot(g.dir, dw)) * (1.0f / g.h));
+        V3 dx = (-dw) + ((g.dir * dot(g.dir, dw)) * ih);
         out.inten_f = (float)(double)(g.alb * ff * ff * brdf);
         V3 t11 = inner * (2 * c2 * c3);
-        t11 = t11 * (1.0f / h5);
+        t11 = t11 * ih5;
         t11 = t11 * brdf;
         t1 = t11 + dx * (ff * ff);
         if (normal_term) {
             gn = ((((g.dir * -2.0f) * c3) * c2) * c2) * brdf;
-            gn = gn * (1.0f / h4);
+            gn = gn * ih4;
             gn = gn + dn * (ff * ff);
             float ct = dot(gn, g.n);
             gn = gn - g.n * ct;
