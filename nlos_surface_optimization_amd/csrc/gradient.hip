@@ -327,10 +327,19 @@ __global__ __launch_bounds__(NT, NLOS_GRAD_WPS) void k_gradient(GradientArgs a) 
                         float c3 = dot(g.n, -g.dir);
                         if (c2 < 0) c2 = 0;
                         if (c3 < 0) c3 = 0;
+#ifdef NLOS_DIAG_GGX_IEEE            // diagnostic builds only: the contract's divisions (rounds 1 - 5)
                         float ff = c2 * c3 / g.h / g.h;
                         double g0;
                         if (MODE == 2) g0 = (double)(g.alb * ff * ff * ggx_eval_adiff(a.sp.ggx_alpha, dot(g.n, -g.dir)));
                         else g0 = (double)(ff * ff);
+#else
+                        // (non-decision arithmetic, round 6: 1-ulp reciprocal, the BRDF derivative in single precision)
+                        const float ihs = rcp_fast(g.h);
+                        float ff = (c2 * c3) * (ihs * ihs);
+                        double g0;
+                        if (MODE == 2) g0 = (double)(g.alb * ff * ff * ggx_eval_adiff_fast(a.sp.ggx_alpha, dot(g.n, -g.dir)));
+                        else g0 = (double)(ff * ff);
+#endif
                         // sum_i w_i (-2) d[bin_i], the taps grouped by bin over the prefix sums of w (the literal
                         // 41-tap loop with one fp64 floor per tap cost 2.5x the rest of the sample)
                         double s0, s1_unused;

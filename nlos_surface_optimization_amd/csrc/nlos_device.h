@@ -464,14 +464,71 @@ __device__ __forceinline__ void ggx_eval_and_nwsdiff_fast(float a, float nw, flo
     s = (Dp * Gv + (2.0f * G1n * G1) * Dv) * 0.25f;
 }
 
+// d brdf / d alpha (scalar alpha gradient of pass 2), the same way
+__device__ __forceinline__ float ggx_eval_adiff_fast(float a, float nw) {
+    if (nw <= 0) return 0.0f;
+    const float Dv = ggx_D_fast(a, nw);
+    if (Dv == 0) return 0.0f;
+    float temp;
+    const float G1 = ggx_G1_fast(a, nw, temp);
+    const float Gv = G1 * G1;
+    const float nw2 = nw * nw, a2 = a * a;
+    const float val = a2 * nw2 - nw2 + 1;
+    const float Dp = -(2.0f * a * (a2 * nw2 + nw2 - 1)) * ggx_rcp(3.14159265358979323846f * val * val * val);
+    float G1a = 0.0f;
+    if (!((nw >= 1.0f) || (nw <= -1.0f))) {
+        const float root = nw + temp;
+        G1a = 2.0f * a * (nw2 - 1.0f) * ggx_rcp(temp * root * root);
+    }
+    return (Dp * Gv + (2.0f * G1a * G1) * Dv) * 0.25f;
+}
+
 // GGX for a (laser, sensor) pair (row N with the GGX branch; the reference has neither a kernel nor a prototype):
 // the half-vector form of the same microfacet model,
 //     brdf(n, wa, wb) = D(n.h) G1(n.wa) G1(n.wb) / 4,   h = (wa + wb) / |wa + wb|,
 // with ggx_confocal.cpp's early-outs; it is ggx_eval() for wa == wb.  GRAD: derivatives with respect to wa, wb
 // (unconstrained) and n from D' = dD/d(n.h), G1' = dG1/d(n.w) (ggx_confocal.cpp:113-150, :176-232).
 struct GgxPair { float brdf; V3 ga, gb, gn; };
-template <bool GRAD>
+// FAST (pass 2's gradient vectors only): the non-decision forms above
+template <bool GRAD, bool FAST = false>
 __device__ __forceinline__ GgxPair ggx_pair(float a, V3 n, V3 wa, V3 wb) {
+    if constexpr (FAST) {
+        GgxPair o;
+        o.brdf = 0.0f;
+        o.ga = o.gb = o.gn = mk(0.0f, 0.0f, 0.0f);
+        const float na = dot(n, wa), nb = dot(n, wb);
+        if (na <= 0 || nb <= 0) return o;
+        const V3 hv = wa + wb;
+        const float h2 = dot(hv, hv);
+        if (!(h2 > 0.0f)) return o;
+        const float ihl = __builtin_amdgcn_rsqf(h2);
+        const V3 hn = hv * ihl;
+        const float nh = dot(n, hn);
+        if (nh <= 0) return o;
+        const float Dv = ggx_D_fast(a, nh);
+        if (Dv == 0) return o;
+        float ta, tb;
+        const float Ga = ggx_G1_fast(a, na, ta), Gb = ggx_G1_fast(a, nb, tb);
+        o.brdf = Dv * Ga * Gb * 0.25f;
+        if (GRAD) {
+            const float a2 = a * a;
+            auto g1n = [&](float nw, float temp) -> float {
+                if ((nw >= 1.0f) || (nw <= -1.0f)) return 0.0f;
+                const float ir = ggx_rcp(nw + temp);
+                return -2.0f * (1.0f - (nw * (a2 - 1.0f)) * ggx_rcp(temp)) * (ir * ir);
+            };
+            const float root = (a2 - 1.0f) * nh * nh + 1.0f;
+            const float Dn = -(4.0f * a2 * nh * (a2 - 1.0f)) * ggx_rcp(3.14159265358979323846f * root * root * root);
+            const float cD = Dn * Ga * Gb * 0.25f;
+            const float cA = Dv * g1n(na, ta) * Gb * 0.25f;
+            const float cB = Dv * Ga * g1n(nb, tb) * 0.25f;
+            const V3 dnh = (n - hn * nh) * ihl;
+            o.ga = (dnh * cD) + (n * cA);
+            o.gb = (dnh * cD) + (n * cB);
+            o.gn = ((hn * cD) + (wa * cA)) + (wb * cB);
+        }
+        return o;
+    }
     GgxPair o;
     o.brdf = 0.0f;
     o.ga = o.gb = o.gn = mk(0.0f, 0.0f, 0.0f);

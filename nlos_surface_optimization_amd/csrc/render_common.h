@@ -388,7 +388,11 @@ __device__ __forceinline__ void grad_vectors_nc(const Face& f, const GeoNC& g, V
         // I = I_lambert * brdf(n, wa, wb), wx = -dirx:  dI/dp = brdf dI_l/dp + I_l (J_a^T ga + J_b^T gb) with
         // J_x = d wx / dp = -(1 - wx wx^T) / d_x;  dI/dn = brdf dI_l/dn + I_l d brdf/dn
         const V3 wa = -g.dirA, wb = -g.dirB;
+#ifdef NLOS_DIAG_GGX_IEEE
         const GgxPair gp = ggx_pair<true>(alpha, g.n, wa, wb);
+#else
+        const GgxPair gp = ggx_pair<true, true>(alpha, g.n, wa, wb);      // (non-decision arithmetic: round 6)
+#endif
         const float il = out.inten_f;
         const V3 pa = fmadd(wa, -dot(wa, gp.ga), gp.ga) * (-i1);
         const V3 pb = fmadd(wb, -dot(wb, gp.gb), gp.gb) * (-i2);
