@@ -73,9 +73,13 @@ def main():
     for name, pairs in (("record_and_combine", False), ("enumerated_pairs", True)):
         def step():
             r.render_product(tl, tln, ts, tsn, tv, tf, num_sample, lb, ub, res, data=data, gradient=grad, zero_gradient=True, pairs=pairs, **gkw)
-        for _ in range(5):
-            step()
-        torch.cuda.synchronize()
+        # (pre-warm: the GPU idled while the CPU oracle ran the gate and its clocks take tens of milliseconds to come back --
+        # without this the first variant's 20 - 30 ms of timed steps read anything between 1.0 and 4.3 ms per step)
+        t_pw = time.perf_counter()
+        while time.perf_counter() - t_pw < 0.5:
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize()
         r.timing_reset()
         t0 = time.perf_counter()
         for _ in range(steps):
