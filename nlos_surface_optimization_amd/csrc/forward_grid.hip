@@ -439,6 +439,14 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
     // round 6: trip counts of the build loops (lane- and wave-iterations) for the dynamic instruction histogram
     unsigned long long c_cnt[2] = {0ull, 0ull}, c_cfw = 0ull, c_fill[2] = {0ull, 0ull}, c_ffw = 0ull;
 #define FWD_WAVE_FIRST() ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1)
+#elif defined(NLOS_FWD_STAMPS_LIGHT)
+    // diagnostic build only (round 6): the six phase stamps alone, taken by thread 0 at barriers the kernel has anyway -- no per-item
+    // clocks, no counters: the phase shares of a workgroup's life in a build that runs at the product's speed (the full stamps
+    // triple the trace's time and with it every share: profiles/r06_light_stamps.log)
+    long long t_prev = clock64();
+    int t_slot = 0;
+    const long long c_start = t_prev;
+#define FWD_STAMP() do { if (tid == 0 && a.dbg) { long long t_now = clock64(); atomicAdd((unsigned long long*)&a.dbg[t_slot], (unsigned long long)(t_now - t_prev)); ++t_slot; t_prev = t_now; } } while (0)
 #else
 #define FWD_STAMP() do { } while (0)
 #endif
@@ -658,6 +666,9 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
             // ---- counting pass -----------------------------------------------------------------------
             int pend_jl = -1;
             uint16_t pend_cov = 0;
+            // (Round 6, measured and removed: requesting the NEXT triangle's record and margin scale before this one is rasterised,
+            // here and in the fill pass -- 1.299 -> 1.300 ms for this pass alone, 1.313 ms with the fill pass as well: the build
+            // phases are 45 % of a workgroup's life (profiles/r06_light_stamps.log) but not because of these round trips.)
             // (Round 4, measured and removed: a pre-pass that applies the reach test to every triangle and compacts the
             // survivors so that the pass proper runs on dense lanes -- the pre-pass repeats projection, bounding box and
             // reach test, and costs more than the idle lanes did: forward 1.334 -> 1.433 ms, profiles/r04_ab_count_compact.log.)
@@ -1488,6 +1499,10 @@ __device__ __forceinline__ bool grid_body(const ForwardArgs& a, const int rows_i
                 if (s_row[i] != 0.0) unsafeAtomicAdd(&grow[i], s_row[i]);     // one partial row per tile
         }
     }
+#ifdef NLOS_FWD_STAMPS_LIGHT
+    __syncthreads();
+    FWD_STAMP();   // 6: waiting for the slowest wave of the trace + header + row flush
+#endif
     return false;
 }
 

@@ -713,7 +713,7 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         fa.tiles_x = fa.tiles_y = side;
         fa.tile_cap = (int)tcap;
     }
-#ifdef NLOS_FWD_STAMPS
+#if defined(NLOS_FWD_STAMPS) || defined(NLOS_FWD_STAMPS_LIGHT)
     HIP_TRY(hipMemsetAsync(c->status.p, 0, 48 * sizeof(long long), st));
     fa.dbg = c->status.as<long long>();     // 40 x int64 (diagnostic build only)
 #endif
@@ -847,6 +847,17 @@ int nlos_render(nlos_ctx* c, const nlos_render_args* a, void* stream) {
         c->geo_stride = fa.geo_stride;
         c->geo_sources = fa.geo_sources;
     }
+#ifdef NLOS_FWD_STAMPS_LIGHT
+    {
+        long long h[48];
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(h, c->status.p, sizeof(h), hipMemcpyDeviceToHost));
+        double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + h[6]);
+        std::fprintf(stderr, "[fwd light stamps] setup %.1f%% count %.1f%% scan %.1f%% fill %.1f%% live-buckets %.1f%% trace (wave 0) %.1f%% tail %.1f%% | Mcycles per source %.3f\n",
+                     100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot, 100 * h[6] / tot,
+                     tot / 1e6 / (double)(L > 0 ? L : 1));
+    }
+#endif
 #ifdef NLOS_FWD_STAMPS
     {
         long long h[48];
